@@ -1,0 +1,251 @@
+// refgen.cpp — golden-vector generator that runs the REFERENCE's own host C++ (compiled from the
+// sources where they lie under /root/reference; nothing is copied into this repo).
+//
+// Test infrastructure.  Built by oracle/Makefile into oracle/_ref/refgen (git-ignored), run by
+// oracle/make_golden.sh, which writes the small fixtures under tests/golden/.
+//
+// What is executed from the reference (all arithmetic below happens inside reference/GLM code):
+//   Splat4D::Splat4D (both ctors)      4DSplatRendering/Splat.h:91-159
+//   Splat3D::Splat3D                   4DSplatRendering/Splat.h:334-344
+//   Camera::GetViewMatrix/GetProjMatrix 4DSplatRendering/Camera.cpp:50-58
+//   VData::parse                       4DSplatRendering/VDataParser.h:25-58
+//   Scenes::GetModelExtrema/GetColor   4DSplatRendering/Scenes.h:58-91   (+ Utils.cpp lerp/mapf/minf/maxf)
+//   Scenes::SplatData::GetMeanInTime   4DSplatRendering/Scenes.h:28-36
+//   glm::quatLookAt / normalize / rotate (vendored GLM 0.9.9.9)
+// What this harness restates itself (loops only, no arithmetic of its own): the per-splat generation loops of
+// LinearMotion::init (Scenes.h:258-279) and NonLinearMotion::init (Scenes.h:517-545) and the key loop
+// (Scenes.h:314-319), because those bodies sit inside methods that also call OpenGL.
+// Not buildable here, therefore not used: anything that needs an OpenGL context or GLEW/GLFW/ImGui
+// libraries (Renderer.cpp, Shader.cpp, the scene classes' init/Render, radix_sort.hpp) and all GLSL.
+//
+// The include block follows Application.cpp:10-57 (order matters: Scenes.h relies on earlier includes).
+#include <GLEW/glew.h>
+#include <GLFW/glfw3.h>
+#include <stdlib.h>
+#include <iostream>
+#include <fstream>
+#include <string>
+#include <sstream>
+#include <algorithm>
+#include <chrono>
+#include <functional>
+#include <memory>
+
+#include "Camera.h"
+#include "Renderer.h"
+#include "VertexBuffer.h"
+#include "IndexBuffer.h"
+#include "VertexArray.h"
+#include "VertexBufferLayout.h"
+#include "Shader.h"
+#include "Geometry.h"
+#include "glm/glm.hpp"
+#include "glm/gtc/matrix_transform.hpp"
+#include <glm/gtc/quaternion.hpp>
+#include <glm/common.hpp>
+#include <glm/gtx/matrix_decompose.hpp>
+#include <glm/gtx/matrix_operation.hpp>
+#include "Splat.h"
+#include "imgui.h"
+#include "Utils.h"
+#include "radix_sort.hpp"
+#include "ShareStorageBuffer.h"
+#include "VDataParser.h"
+#include "Scene.h"
+#include "Scenes.h"
+
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+static std::string g_out;
+static FILE* g_manifest = nullptr;
+static bool g_first = true;
+
+static uint32_t crc32_buf(const void* data, size_t n) {
+    static uint32_t table[256]; static bool init = false;
+    if (!init) { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; } init = true; }
+    uint32_t c = 0xFFFFFFFFu; const uint8_t* p = (const uint8_t*)data;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 255] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+static void dump(const char* name, const char* dtype, const void* data, size_t count, size_t cols) {
+    std::string path = g_out + "/" + name + ".bin";
+    FILE* f = fopen(path.c_str(), "wb"); if (!f) { perror(path.c_str()); exit(1); }
+    fwrite(data, 4, count, f); fclose(f);
+    fprintf(g_manifest, "%s\n  \"%s\": {\"dtype\": \"%s\", \"count\": %zu, \"cols\": %zu, \"crc32\": %u}", g_first ? "" : ",", name, dtype, count, cols, crc32_buf(data, 4 * count));
+    g_first = false;
+}
+static void note(const char* name, const char* json_value) {
+    fprintf(g_manifest, "%s\n  \"%s\": %s", g_first ? "" : ",", name, json_value); g_first = false;
+}
+
+// deterministic parameter stream for the ctor grids (values only feed the reference ctors)
+static uint64_t sm_state = 0x9E3779B97F4A7C15ull;
+static float urand(float lo, float hi) {
+    uint64_t z = (sm_state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+    return lo + (hi - lo) * u;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) { fprintf(stderr, "usage: refgen <reference_root> <out_dir>\n"); return 2; }
+    std::string root = argv[1]; g_out = argv[2];
+    g_manifest = fopen((g_out + "/manifest.json").c_str(), "w");
+    fprintf(g_manifest, "{");
+
+    // ---- (1) Splat4D ctor-2 grid: in = {quat wxyz, scale3, lifetime, fade, dir3} (12), out = cov16
+    {
+        const int N = 64; std::vector<float> in, out;
+        for (int i = 0; i < N; ++i) {
+            glm::quat q(urand(-1, 1), urand(-1, 1), urand(-1, 1), urand(-1, 1));     // w,x,y,z
+            if (i % 2 == 0) q = glm::normalize(q);
+            glm::vec3 sc(urand(0.2f, 5.0f), urand(0.2f, 5.0f), urand(0.2f, 5.0f));
+            float life = urand(0.3f, 3.0f);
+            float fade = (i % 3 == 0) ? 0.5f : urand(0.05f, 0.95f);
+            glm::vec3 dir(urand(-5, 5), urand(-5, 5), urand(-5, 5));
+            Splat4D s(glm::vec4(1, 2, 3, 4), q, sc, life, fade, dir, glm::vec4(1));
+            glm::mat4 g = s.GetGeoInfo();
+            float rowin[12] = { q.w, q.x, q.y, q.z, sc.x, sc.y, sc.z, life, fade, dir.x, dir.y, dir.z };
+            in.insert(in.end(), rowin, rowin + 12);
+            out.insert(out.end(), &g[0][0], &g[0][0] + 16);
+        }
+        dump("splat4d_ctor2_in", "f32", in.data(), in.size(), 12);
+        dump("splat4d_ctor2_cov", "f32", out.data(), out.size(), 16);
+    }
+    // ---- (2) Splat4D ctor-1 (two quaternions): in = {q0 wxyz, q1 wxyz, scale4} (12), out = cov16
+    {
+        const int N = 32; std::vector<float> in, out;
+        for (int i = 0; i < N; ++i) {
+            glm::quat q0(urand(-1, 1), urand(-1, 1), urand(-1, 1), urand(-1, 1));
+            glm::quat q1(urand(-1, 1), urand(-1, 1), urand(-1, 1), urand(-1, 1));
+            glm::vec4 sc(urand(0.2f, 4.0f), urand(0.2f, 4.0f), urand(0.2f, 4.0f), urand(0.2f, 4.0f));
+            Splat4D s(glm::vec4(0), q0, q1, sc, glm::vec4(1));
+            glm::mat4 g = s.GetGeoInfo();
+            float rowin[12] = { q0.w, q0.x, q0.y, q0.z, q1.w, q1.x, q1.y, q1.z, sc.x, sc.y, sc.z, sc.w };
+            in.insert(in.end(), rowin, rowin + 12);
+            out.insert(out.end(), &g[0][0], &g[0][0] + 16);
+        }
+        dump("splat4d_ctor1_in", "f32", in.data(), in.size(), 12);
+        dump("splat4d_ctor1_cov", "f32", out.data(), out.size(), 16);
+    }
+    // ---- (3) Splat3D ctor: in = {quat wxyz, scale3} (7), out = cov9 ; and quatLookAt: in = {n3}, out = quat wxyz
+    {
+        const int N = 64; std::vector<float> in, out, nin, qout;
+        for (int i = 0; i < N; ++i) {
+            glm::quat q(urand(-1, 1), urand(-1, 1), urand(-1, 1), urand(-1, 1));
+            if (i % 2 == 0) q = glm::normalize(q);
+            glm::vec3 sc(urand(0.2f, 5.0f), urand(0.2f, 5.0f), urand(0.2f, 5.0f));
+            Splat3D s(glm::vec4(0, 0, 0, 1), q, sc, glm::vec4(1));
+            glm::mat3 g = s.GetGeoInfo();
+            float rowin[7] = { q.w, q.x, q.y, q.z, sc.x, sc.y, sc.z };
+            in.insert(in.end(), rowin, rowin + 7);
+            out.insert(out.end(), &g[0][0], &g[0][0] + 9);
+            glm::vec3 n(urand(-1, 1), urand(-1, 1), urand(-1, 1));
+            if (i == 0) n = glm::vec3(0, 1, 0);              // degenerate: parallel to up
+            if (i == 1) n = glm::vec3(0, -1, 0);
+            glm::quat ql = glm::normalize(glm::quatLookAt(glm::normalize(n), glm::vec3(0, 1, 0)));   // Scenes.h:268
+            nin.insert(nin.end(), { n.x, n.y, n.z });
+            qout.insert(qout.end(), { ql.w, ql.x, ql.y, ql.z });
+        }
+        dump("splat3d_ctor_in", "f32", in.data(), in.size(), 7);
+        dump("splat3d_ctor_cov", "f32", out.data(), out.size(), 9);
+        dump("quatlookat_in", "f32", nin.data(), nin.size(), 3);
+        dump("quatlookat_q", "f32", qout.data(), qout.size(), 4);
+    }
+    // ---- (4) Camera matrices: in = {w,h,pos3,ori3,far} (9), out = view16 + proj16
+    {
+        struct Cam { int w, h; glm::vec3 p, o; float far_; };
+        Cam cams[] = {
+            { 1920, 1080, { 60, 90, 90 }, { 0, -1, -1 }, 5000.0f },                                         // LinearMotion  Scenes.h:228-229
+            { 1920, 1080, { 551.58f, 350.43f, -184.33f }, { -0.774978f, -0.570354f, 0.272222f }, 5000.0f }, // README screenshot camera
+            { 3840, 2160, { 0, 60, 60 }, { 0, -1, -1 }, 5000.0f },                                          // NonLinearMotion Scenes.h:493-494
+            { 800, 800, { 0, 0, 10 }, { 0, 0, -1 }, 256.0f },                                               // Camera.h defaults
+        };
+        std::vector<float> in, out;
+        for (auto& c : cams) {
+            Camera cam(c.w, c.h, c.p, c.o);
+            cam.SetFar(c.far_);                                                                           // Application.cpp:126
+            glm::mat4 v = cam.GetViewMatrix(), p = cam.GetProjMatrix();
+            float rowin[9] = { (float)c.w, (float)c.h, c.p.x, c.p.y, c.p.z, c.o.x, c.o.y, c.o.z, c.far_ };
+            in.insert(in.end(), rowin, rowin + 9);
+            out.insert(out.end(), &v[0][0], &v[0][0] + 16);
+            out.insert(out.end(), &p[0][0], &p[0][0] + 16);
+        }
+        dump("camera_in", "f32", in.data(), in.size(), 9);
+        dump("camera_viewproj", "f32", out.data(), out.size(), 32);
+    }
+    // ---- (5) VData::parse(teapot): all records as 6 floats (pos, normal)
+    std::vector<glm::mat3> model = VData::parse(root + "/Objects/teapot.vdata");
+    {
+        std::vector<float> flat;
+        for (auto& m : model) flat.insert(flat.end(), { m[0][0], m[0][1], m[0][2], m[1][0], m[1][1], m[1][2] });
+        dump("teapot_vdata", "f32", flat.data(), flat.size(), 6);
+        char buf[64]; snprintf(buf, sizeof buf, "%zu", model.size()); note("teapot_vertices", buf);
+    }
+    // ---- (6) LinearMotion SSBO (Scenes.h:258-279) with the class defaults (Scenes.h:186-201)
+    std::vector<Scenes::SplatData> lin;
+    {
+        const int steps = 50; const float mult = 1.0f, oscale = 5.0f, sx = 4.0f, sy = 4.0f, sz = 1.0f, life = 1.0f, fade = 0.5f, speed = 1.0f;
+        ModelEdges medge = Scenes::GetModelExtrema(model);
+        for (int dt = 0; dt < steps; ++dt)
+            for (int i = 0; i < (int)model.size(); ++i) {
+                glm::vec3 pos = model[i][0];
+                glm::vec3 dir{ 1.0, 0.0, 0.0 };
+                glm::vec3 timeOffset = dir * float(dt * mult);
+                Splat4D s4d{ glm::vec4{ (oscale * pos) + timeOffset, float(dt) },
+                             glm::normalize(glm::quatLookAt(glm::normalize(model[i][1]), glm::vec3(0, 1, 0))),
+                             glm::vec3{ sx, sy, sz }, life, fade, glm::normalize(dir) * speed,
+                             Scenes::GetColor(pos, medge, model[i][1]) };
+                lin.push_back({ s4d.GetPosititon(), s4d.GetColor(), s4d.GetGeoInfo() });
+            }
+        static_assert(sizeof(Scenes::SplatData) == 96, "SplatData must be 96 bytes");
+        dump("linear_first1000", "f32", lin.data(), 1000 * 24, 24);
+        dump("linear_block25_first200", "f32", lin.data() + 25 * model.size(), 200 * 24, 24);
+        char buf[128]; snprintf(buf, sizeof buf, "{\"records\": %zu, \"crc32\": %u}", lin.size(), crc32_buf(lin.data(), lin.size() * 96)); note("linear_full", buf);
+    }
+    // ---- (7) key/value uploads of the key loop (Scenes.h:314-319) for t in {0, 12.5, 49}, camera (60,90,90)
+    {
+        glm::vec3 campos{ 60, 90, 90 };
+        float ts[3] = { 0.0f, 12.5f, 49.0f };
+        for (int k = 0; k < 3; ++k) {
+            std::vector<float> keys(lin.size());
+            for (int i = 0; i < (int)lin.size(); ++i) {
+                glm::vec4 tmp = lin[i].GetMeanInTime(ts[k]) - glm::vec4(campos, 1);
+                keys[i] = 1.0f / sqrtf(tmp.x * tmp.x + tmp.y * tmp.y + tmp.z * tmp.z);
+            }
+            char nm[64]; snprintf(nm, sizeof nm, "linear_keys_t%d_first4000", k);
+            dump(nm, "f32", keys.data(), 4000, 1);
+            snprintf(nm, sizeof nm, "linear_keys_t%d_block25_first200", k);
+            dump(nm, "f32", keys.data() + 25 * model.size(), 200, 1);
+            char buf[128]; snprintf(buf, sizeof buf, "{\"t\": %g, \"crc32\": %u}", ts[k], crc32_buf(keys.data(), keys.size() * 4));
+            snprintf(nm, sizeof nm, "linear_keys_t%d_full", k); note(nm, buf);
+        }
+    }
+    // ---- (8) NonLinearMotion SSBO (Scenes.h:517-545) with the class defaults (Scenes.h:451-467)
+    {
+        const int steps = 92; const float oscale = 5.0f, sx = 4.0f, sy = 4.0f, sz = 1.0f, life = 1.0f, fade = 0.5f, speed = 20.0f, radius = 20.0f, amul = 4.0f;
+        std::vector<Scenes::SplatData> nl;
+        ModelEdges medge = Scenes::GetModelExtrema(model);
+        for (int dt = 0; dt < steps; ++dt)
+            for (int i = 0; i < (int)model.size(); ++i) {
+                glm::vec3 pos = model[i][0];
+                glm::vec4 forward{ 1.0, 0.0, 0.0, 0.0 };
+                glm::vec3 timeOffset = glm::vec3{ glm::rotate(forward, glm::radians(float(dt * amul)), { 0.0, 1.0, 0.0 }) };
+                glm::vec3 timeOffset_next = glm::vec3{ glm::rotate(forward, glm::radians(float((dt + 1) * amul)), { 0.0, 1.0, 0.0 }) };
+                Splat4D s4d{ glm::vec4{ (oscale * pos) + (timeOffset * radius), float(dt) },
+                             glm::normalize(glm::quatLookAt(glm::normalize(model[i][1]), glm::vec3(0, 1, 0))),
+                             glm::vec3{ sx, sy, sz }, life, fade, (timeOffset_next - timeOffset) * speed,
+                             Scenes::GetColor(pos, medge, model[i][1]) };
+                nl.push_back({ s4d.GetPosititon(), s4d.GetColor(), s4d.GetGeoInfo() });
+            }
+        dump("nonlinear_first500", "f32", nl.data(), 500 * 24, 24);
+        dump("nonlinear_block45_first200", "f32", nl.data() + 45 * model.size(), 200 * 24, 24);
+        char buf[128]; snprintf(buf, sizeof buf, "{\"records\": %zu, \"crc32\": %u}", nl.size(), crc32_buf(nl.data(), nl.size() * 96)); note("nonlinear_full", buf);
+    }
+    fprintf(g_manifest, "\n}\n"); fclose(g_manifest);
+    printf("refgen: fixtures written to %s\n", g_out.c_str());
+    return 0;
+}
