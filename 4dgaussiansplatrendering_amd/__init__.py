@@ -1,0 +1,281 @@
+"""4dgaussiansplatrendering_amd — ctypes binding of libgs4d.so (include/gs4d.h).
+
+The product is the HIP library; this module is plumbing for the tests and bench.py.  It has no CPU
+fallback: importing it without the built library, or creating a Context without a GPU, raises.
+
+(The directory name starts with a digit, so import it with
+``importlib.import_module("4dgaussiansplatrendering_amd")``.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgs4d.so")
+
+MODE_4D_SORTED, MODE_4D_DIRECT, MODE_3D_FULL, MODE_2D = 0, 1, 2, 3
+U_TIME, U_MIN_OPACITY = 0, 1
+U_VIEW, U_PROJ = 0, 1
+KEY_REF_INV_EUCLID, KEY_VIEW_Z = 0, 1
+SRC_ALPHA, ONE_MINUS_SRC_ALPHA = 0x0302, 0x0303
+STAGES = ("keygen", "sort", "preprocess", "binning", "pairsort", "composite")
+CLEAR_COLOR = (0.18431373, 0.20784314, 0.25882353, 1.0)   # Application.cpp:125
+
+
+class Gs4dError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make lib` (or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, sz, u32, i32, f32 = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.c_float
+    sig = {
+        "gs4d_create": (i32, [i32, i32, i32, C.POINTER(vp)]),
+        "gs4d_destroy": (None, [vp]),
+        "gs4d_resize": (i32, [vp, i32, i32]),
+        "gs4d_last_error": (C.c_char_p, [vp]),
+        "gs4d_buffer_create": (i32, [vp, vp, sz, C.POINTER(u32)]),
+        "gs4d_buffer_subdata": (i32, [vp, u32, sz, vp, sz]),
+        "gs4d_buffer_read": (i32, [vp, u32, sz, vp, sz]),
+        "gs4d_buffer_destroy": (i32, [vp, u32]),
+        "gs4d_buffer_device_ptr": (i32, [vp, u32, C.POINTER(vp), C.POINTER(sz)]),
+        "gs4d_bind_storage": (i32, [vp, i32, u32]),
+        "gs4d_set_mode": (i32, [vp, i32]),
+        "gs4d_set_uniform_1f": (i32, [vp, i32, f32]),
+        "gs4d_set_uniform_mat4": (i32, [vp, i32, vp]),
+        "gs4d_set_clear_color": (i32, [vp, vp]),
+        "gs4d_set_blend": (i32, [vp, i32, i32]),
+        "gs4d_clear": (i32, [vp]),
+        "gs4d_sort_pairs": (i32, [vp, u32, u32, sz]),
+        "gs4d_keygen": (i32, [vp, u32, f32, vp, u32, u32, sz, i32]),
+        "gs4d_draw_instanced": (i32, [vp, sz]),
+        "gs4d_draw_quads": (i32, [vp, u32, sz]),
+        "gs4d_read_pixels": (i32, [vp, vp, sz]),
+        "gs4d_read_pixels_device": (i32, [vp, vp, sz]),
+        "gs4d_read_pixels_rgba8_device": (i32, [vp, vp, sz]),
+        "gs4d_set_stream": (i32, [vp, vp]),
+        "gs4d_finish": (i32, [vp]),
+        "gs4d_set_profiling": (i32, [vp, i32]),
+        "gs4d_get_timings": (i32, [vp, vp]),
+        "gs4d_get_stats": (i32, [vp, vp]),
+        "gs4d_debug_read_projected": (i32, [vp, vp, sz]),
+        "gs4d_host_look_at": (None, [vp, vp, vp, vp]),
+        "gs4d_host_perspective": (None, [f32, i32, i32, f32, f32, vp]),
+        "gs4d_host_quat_look_at": (None, [vp, vp, vp]),
+        "gs4d_host_splat3d_cov": (None, [vp, vp, vp]),
+        "gs4d_host_splat4d_cov": (None, [vp, vp, f32, f32, vp, vp]),
+        "gs4d_host_splat4d_cov2q": (None, [vp, vp, vp, vp]),
+        "gs4d_host_build_records_3d": (None, [sz, vp, vp, vp, vp, vp]),
+        "gs4d_host_build_records_4d": (None, [sz, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "gs4d_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export what gs4d.h declares
+        fn.restype, fn.argtypes = res, args
+    return lib, tuple(sig)
+
+
+_lib, EXPORTS = _load()
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---- host-side parameterisation (CPU code in libgs4d.so; Splat.h / Camera.cpp mirror) ---------------
+def look_at(eye, orientation, up=(0.0, 1.0, 0.0)):
+    out = np.zeros(16, np.float32)
+    _lib.gs4d_host_look_at(_ptr(_f32(eye)), _ptr(_f32(orientation)), _ptr(_f32(up)), _ptr(out))
+    return out
+
+
+def perspective(fov_deg, width, height, znear, zfar):
+    out = np.zeros(16, np.float32)
+    _lib.gs4d_host_perspective(fov_deg, width, height, znear, zfar, _ptr(out))
+    return out
+
+
+def quat_look_at(direction, up=(0.0, 1.0, 0.0)):
+    out = np.zeros(4, np.float32)
+    _lib.gs4d_host_quat_look_at(_ptr(_f32(direction)), _ptr(_f32(up)), _ptr(out))
+    return out
+
+
+def splat3d_cov(q_wxyz, scale3):
+    out = np.zeros(9, np.float32)
+    _lib.gs4d_host_splat3d_cov(_ptr(_f32(q_wxyz)), _ptr(_f32(scale3)), _ptr(out))
+    return out
+
+
+def splat4d_cov(q_wxyz, scale3, lifetime, fade, dir3):
+    out = np.zeros(16, np.float32)
+    _lib.gs4d_host_splat4d_cov(_ptr(_f32(q_wxyz)), _ptr(_f32(scale3)), lifetime, fade, _ptr(_f32(dir3)), _ptr(out))
+    return out
+
+
+def splat4d_cov2q(q0, q1, scale4):
+    out = np.zeros(16, np.float32)
+    _lib.gs4d_host_splat4d_cov2q(_ptr(_f32(q0)), _ptr(_f32(q1)), _ptr(_f32(scale4)), _ptr(out))
+    return out
+
+
+def build_records_3d(pos3, q_wxyz, scale3, rgba):
+    pos3, q, s, col = _f32(pos3).reshape(-1, 3), _f32(q_wxyz).reshape(-1, 4), _f32(scale3).reshape(-1, 3), _f32(rgba).reshape(-1, 4)
+    n = pos3.shape[0]
+    assert q.shape[0] == n and s.shape[0] == n and col.shape[0] == n
+    rec = np.empty((n, 24), np.float32)
+    _lib.gs4d_host_build_records_3d(n, _ptr(pos3), _ptr(q), _ptr(s), _ptr(col), _ptr(rec))
+    return rec
+
+
+def build_records_4d(pos4, q_wxyz, scale3, lifetime, fade, dir3, rgba):
+    pos4, q, s = _f32(pos4).reshape(-1, 4), _f32(q_wxyz).reshape(-1, 4), _f32(scale3).reshape(-1, 3)
+    life, fd, d, col = _f32(lifetime).reshape(-1), _f32(fade).reshape(-1), _f32(dir3).reshape(-1, 3), _f32(rgba).reshape(-1, 4)
+    n = pos4.shape[0]
+    assert all(x.shape[0] == n for x in (q, s, life, fd, d, col))
+    rec = np.empty((n, 24), np.float32)
+    _lib.gs4d_host_build_records_4d(n, _ptr(pos4), _ptr(q), _ptr(s), _ptr(life), _ptr(fd), _ptr(d), _ptr(col), _ptr(rec))
+    return rec
+
+
+# ---- device context -----------------------------------------------------------------------------
+class Context:
+    """One GPU, one HIP stream, one RGBA32F framebuffer (gs4d_ctx)."""
+
+    def __init__(self, width, height, device=0):
+        h = C.c_void_p()
+        rc = _lib.gs4d_create(device, width, height, C.byref(h))
+        if rc != 0:
+            raise Gs4dError(f"gs4d_create failed ({rc}): {_lib.gs4d_last_error(None).decode()}")
+        self._h = h
+        self.width, self.height = width, height
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.gs4d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise Gs4dError(f"gs4d error {rc}: {_lib.gs4d_last_error(self._h).decode()}")
+
+    # buffers
+    def buffer(self, data=None, nbytes=None):
+        name = C.c_uint32()
+        if data is not None:
+            a = np.ascontiguousarray(data)
+            self._chk(_lib.gs4d_buffer_create(self._h, _ptr(a), a.nbytes, C.byref(name)))
+        else:
+            self._chk(_lib.gs4d_buffer_create(self._h, None, nbytes, C.byref(name)))
+        return name.value
+
+    def subdata(self, buf, data, offset=0):
+        a = np.ascontiguousarray(data)
+        self._chk(_lib.gs4d_buffer_subdata(self._h, buf, offset, _ptr(a), a.nbytes))
+
+    def read(self, buf, dtype, count, offset=0):
+        out = np.empty(count, dtype)
+        self._chk(_lib.gs4d_buffer_read(self._h, buf, offset, _ptr(out), out.nbytes))
+        return out
+
+    def delete(self, buf):
+        self._chk(_lib.gs4d_buffer_destroy(self._h, buf))
+
+    def device_ptr(self, buf):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(_lib.gs4d_buffer_device_ptr(self._h, buf, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bind(self, slot, buf):
+        self._chk(_lib.gs4d_bind_storage(self._h, slot, buf))
+
+    # state
+    def set_mode(self, mode):
+        self._chk(_lib.gs4d_set_mode(self._h, mode))
+
+    def set_uniforms(self, time=None, min_opacity=None, view=None, proj=None):
+        if time is not None:
+            self._chk(_lib.gs4d_set_uniform_1f(self._h, U_TIME, time))
+        if min_opacity is not None:
+            self._chk(_lib.gs4d_set_uniform_1f(self._h, U_MIN_OPACITY, min_opacity))
+        if view is not None:
+            self._chk(_lib.gs4d_set_uniform_mat4(self._h, U_VIEW, _ptr(_f32(view))))
+        if proj is not None:
+            self._chk(_lib.gs4d_set_uniform_mat4(self._h, U_PROJ, _ptr(_f32(proj))))
+
+    def set_clear_color(self, rgba):
+        self._chk(_lib.gs4d_set_clear_color(self._h, _ptr(_f32(rgba))))
+
+    def set_blend(self, src, dst):
+        self._chk(_lib.gs4d_set_blend(self._h, src, dst))
+
+    def clear(self):
+        self._chk(_lib.gs4d_clear(self._h))
+
+    def resize(self, width, height):
+        self._chk(_lib.gs4d_resize(self._h, width, height))
+        self.width, self.height = width, height
+
+    # ordering
+    def sort_pairs(self, keys, vals, n):
+        self._chk(_lib.gs4d_sort_pairs(self._h, keys, vals, n))
+
+    def keygen(self, data, t, cam_pos, keys, idx, n, key_mode=KEY_REF_INV_EUCLID):
+        self._chk(_lib.gs4d_keygen(self._h, data, t, _ptr(_f32(cam_pos)), keys, idx, n, key_mode))
+
+    # draw / read-back
+    def draw_instanced(self, instances):
+        self._chk(_lib.gs4d_draw_instanced(self._h, instances))
+
+    def draw_quads(self, vertices, nquads):
+        self._chk(_lib.gs4d_draw_quads(self._h, vertices, nquads))
+
+    def read_pixels(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._chk(_lib.gs4d_read_pixels(self._h, _ptr(out), out.nbytes))
+        return out
+
+    def read_pixels_device(self, dptr, nbytes):
+        self._chk(_lib.gs4d_read_pixels_device(self._h, C.c_void_p(dptr), nbytes))
+
+    def read_pixels_rgba8_device(self, dptr, nbytes):
+        self._chk(_lib.gs4d_read_pixels_rgba8_device(self._h, C.c_void_p(dptr), nbytes))
+
+    def set_stream(self, hip_stream):
+        self._chk(_lib.gs4d_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def finish(self):
+        self._chk(_lib.gs4d_finish(self._h))
+
+    # measurement
+    def set_profiling(self, on):
+        self._chk(_lib.gs4d_set_profiling(self._h, 1 if on else 0))
+
+    def timings(self):
+        ms = np.zeros(len(STAGES), np.float32)
+        self._chk(_lib.gs4d_get_timings(self._h, _ptr(ms)))
+        return dict(zip(STAGES, (float(x) for x in ms)))
+
+    def stats(self):
+        st = np.zeros(4, np.uint64)
+        self._chk(_lib.gs4d_get_stats(self._h, _ptr(st)))
+        return {"entries": int(st[0]), "capacity": int(st[1]), "reruns": int(st[2]), "tiles": int(st[3])}
+
+    def debug_projected(self, n):
+        out = np.empty((n, 16), np.float32)
+        self._chk(_lib.gs4d_debug_read_projected(self._h, _ptr(out), n))
+        return out
+
+
+def version():
+    return _lib.gs4d_version().decode()

@@ -1,0 +1,563 @@
+// gs4d_api.hip — the C ABI (include/gs4d.h): context, buffer objects, pipeline state and the draw sequence.
+//
+// Stands in for the OpenGL objects and calls the reference's scenes use on this path:
+//   ShareStorageBuffer ctor/SubData/Bind                    4DSplatRendering/ShareStorageBuffer.cpp:3-40
+//   glGenBuffers/glBufferStorage/glBufferSubData/glBindBufferBase/glDeleteBuffers in the scenes   Scenes.h:241-247, 282-283, 321-325, 336, 220-224
+//   Shader::Bind/SetUniform1f/SetUniformMat4f               4DSplatRendering/Shader.cpp:171-174, 206-209
+//   radix_sort::sorter::sort                                Dependencies/GPU_RADIX_SORT/radix_sort.hpp:258-392
+//   Renderer::Clear / Renderer::Draw                        4DSplatRendering/Renderer.cpp:20-39
+// One HIP stream per context; API calls enqueue work in order and return; only read-back/finish calls block, plus the
+// validation of a draw's tile-list capacity, which is deferred to the next call that could observe it (see resolve_pending).
+#include "gs4d_internal.h"
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <algorithm>
+
+using namespace gs4d;
+
+namespace {
+
+struct Buffer {
+    void* d = nullptr;
+    size_t bytes = 0;
+    uint64_t version = 0;          // bumped by every write; SoA shadow and pending-draw tracking compare against it
+    float4* soa = nullptr;         // lazily built SoA shadow of 96-B SplatData records
+    size_t soa_n = 0;
+    uint64_t soa_version = ~0ull;
+    bool alive = false;
+};
+
+struct DrawArgs {
+    int mode = 0;
+    Uniforms u;
+    gs4d_buf data = 0, order = 0;
+    uint64_t data_version = 0, order_version = 0;
+    size_t instances = 0;
+    bool quads = false;
+    bool fb_was_clear = false;     // framebuffer state the composite of this draw must start from (kept for a re-run)
+};
+
+thread_local std::string g_create_error;
+
+} // namespace
+
+struct gs4d_ctx {
+    int device = 0;
+    int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
+    hipStream_t st = nullptr;          // stream in use (own_st unless the caller supplied one)
+    hipStream_t own_st = nullptr;
+    std::string err;
+    std::vector<Buffer> bufs;          // index = name; bufs[0] unused
+    gs4d_buf slots[8] = { 0 };
+    int mode = GS4D_MODE_4D_SORTED;
+    Uniforms u;
+    float clear[4] = { 0.0f, 0.0f, 0.0f, 0.0f };     // GL's initial clear colour; the app sets its own (Application.cpp:125)
+    float4* fb = nullptr;
+    bool fb_is_clear = true;           // framebuffer content == clear colour, not yet materialised
+    // per-draw scratch
+    float4* proj = nullptr; size_t proj_cap = 0; size_t proj_n = 0;
+    uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;
+    SortScratch depth_sort, pair_sort;
+    BinScratch bin;
+    uint32_t* host_total = nullptr;    // pinned, 4 words
+    hipEvent_t pending_ev = nullptr;
+    bool pending = false;
+    DrawArgs pending_args;
+    uint64_t stat_entries = 0, stat_reruns = 0;
+    // profiling
+    // profiling: a ring of per-frame event pairs; a frame ends with its draw
+    static constexpr int PROF_FRAMES = 128;
+    bool profiling = false;
+    int prof_frame = 0;
+    std::vector<hipEvent_t> ev0, ev1;          // [PROF_FRAMES][GS4D_T_COUNT], created on first use
+    std::vector<uint8_t> ran;
+};
+
+namespace {
+
+int fail(gs4d_ctx* c, int code, const char* msg) { if (c) c->err = msg; else g_create_error = msg; return code; }
+int hipfail(gs4d_ctx* c, hipError_t e, const char* where) {
+    char b[256]; snprintf(b, sizeof b, "%s: %s", where, hipGetErrorString(e));
+    if (c) c->err = b; else g_create_error = b;
+    return e == hipErrorOutOfMemory ? GS4D_E_NOMEM : GS4D_E_DEVICE;
+}
+#define HIPCHK(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hipfail((c), e__, #call); } while (0)
+
+Buffer* getbuf(gs4d_ctx* c, gs4d_buf b) { return (b != 0 && b < c->bufs.size() && c->bufs[b].alive) ? &c->bufs[b] : nullptr; }
+
+struct StageTimer {
+    gs4d_ctx* c; int slot;
+    StageTimer(gs4d_ctx* c_, int id) : c(c_), slot(-1) {
+        if (c->profiling && c->prof_frame < gs4d_ctx::PROF_FRAMES) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], c->st); }
+    }
+    ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(c->ev1[slot], c->st); c->ran[slot] = 1; } }
+};
+
+int ensure_soa(gs4d_ctx* c, Buffer& b) {
+    const size_t n = b.bytes / 96;
+    if (b.soa && b.soa_n == n && b.soa_version == b.version) return GS4D_OK;
+    if (!b.soa || b.soa_n != n) {
+        if (b.soa) { HIPCHK(c, hipStreamSynchronize(c->st)); (void)hipFree(b.soa); b.soa = nullptr; }
+        if (n) HIPCHK(c, hipMalloc(&b.soa, n * 96));
+        b.soa_n = n;
+    }
+    HIPCHK(c, launch_soa_repack(c->st, (const float*)b.d, n, b.soa));
+    b.soa_version = b.version;
+    return GS4D_OK;
+}
+
+int ensure_pairs(gs4d_ctx* c, size_t cap) {
+    if (c->pair_cap >= cap) return GS4D_OK;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->pair_keys) (void)hipFree(c->pair_keys);
+    if (c->pair_vals) (void)hipFree(c->pair_vals);
+    c->pair_keys = c->pair_vals = nullptr; c->pair_cap = 0;
+    HIPCHK(c, hipMalloc(&c->pair_keys, cap * 4));
+    HIPCHK(c, hipMalloc(&c->pair_vals, cap * 4));
+    c->pair_cap = cap;
+    return GS4D_OK;
+}
+
+// Enqueue binning -> tile sort -> ranges -> composite for projected records already in c->proj.
+int enqueue_raster(gs4d_ctx* c, const uint32_t* order, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear) {
+    const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    HIPCHK(c, bin_scratch_reserve(c->bin, ninst, ntiles));
+    {
+        StageTimer t(c, GS4D_T_BINNING);
+        HIPCHK(c, launch_binning(c->st, c->bin, c->proj, order, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap));
+    }
+    int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
+    {
+        StageTimer t(c, GS4D_T_PAIRSORT);
+        HIPCHK(c, radix_sort_pairs(c->st, c->pair_sort, c->pair_keys, c->pair_vals, c->pair_cap, c->bin.total, tile_bits));
+        HIPCHK(c, launch_tile_ranges(c->st, c->bin, c->pair_keys, c->pair_cap, ntiles));
+    }
+    {
+        StageTimer t(c, GS4D_T_COMPOSITE);
+        HIPCHK(c, launch_composite(c->st, c->proj, c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->host_total, c->bin.total, 16, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipEventRecord(c->pending_ev, c->st));
+    return GS4D_OK;
+}
+
+int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
+    Buffer* data = getbuf(c, a.data);
+    if (!data) return fail(c, GS4D_E_INVALID, "draw: no splat data buffer bound");
+    const uint32_t* order = nullptr;
+    size_t nrec = 0, npre = 0;
+    int premult = 0;
+    if (a.quads) { nrec = data->bytes / 288; npre = nrec < a.instances ? nrec : a.instances; premult = 1; }
+    else if (a.mode == GS4D_MODE_4D_SORTED) {
+        Buffer* ob = getbuf(c, a.order);
+        if (!ob) return fail(c, GS4D_E_INVALID, "draw: GS4D_MODE_4D_SORTED needs the sort-index buffer at slot 1");
+        if (ob->bytes < a.instances * 4) return fail(c, GS4D_E_INVALID, "draw: sort-index buffer smaller than the instance count");
+        order = (const uint32_t*)ob->d;
+        nrec = data->bytes / 96; npre = nrec;
+    } else if (a.mode == GS4D_MODE_4D_DIRECT) { nrec = data->bytes / 96; npre = nrec < a.instances ? nrec : a.instances; }
+    else if (a.mode == GS4D_MODE_2D) { nrec = data->bytes / 48; npre = nrec < a.instances ? nrec : a.instances; }
+    else return fail(c, GS4D_E_INVALID, "draw: mode does not match the draw call");
+    if (a.instances == 0 || nrec == 0) return GS4D_OK;
+    if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
+
+    if (preprocess) {
+        if (c->proj_cap < npre) {
+            HIPCHK(c, hipStreamSynchronize(c->st));
+            if (c->proj) (void)hipFree(c->proj);
+            c->proj = nullptr; c->proj_cap = 0;
+            HIPCHK(c, hipMalloc(&c->proj, npre * 64));
+            c->proj_cap = npre;
+        }
+        if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
+        StageTimer t(c, GS4D_T_PREPROCESS);
+        if (a.quads) HIPCHK(c, launch_preprocess_3d(c->st, (const float*)data->d, npre, a.u, c->W, c->H, c->proj));
+        else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->st, (const float*)data->d, npre, a.u, c->W, c->H, c->proj));
+        else HIPCHK(c, launch_preprocess_4d(c->st, data->soa, npre, a.u, c->W, c->H, c->proj));
+        c->proj_n = npre;
+    }
+    size_t want = a.instances * 2 + 65536;
+    if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
+    if (c->pair_cap < want) { int rc = ensure_pairs(c, want); if (rc) return rc; }
+    return enqueue_raster(c, order, a.instances, npre, premult, a.fb_was_clear);
+}
+
+// A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
+// Called by every entry point that could observe the draw's result or overwrite its inputs.  On overflow the raster stages are
+// re-run with exact capacity (the projected records are still valid; inputs are unchanged by construction).
+int resolve_pending(gs4d_ctx* c) {
+    while (c->pending) {
+        HIPCHK(c, hipEventSynchronize(c->pending_ev));
+        c->pending = false;
+        const uint64_t total = (uint64_t)c->host_total[2] | ((uint64_t)c->host_total[3] << 32);
+        if (!c->host_total[1]) { c->stat_entries = total; break; }
+        if (total >= 0xFFFFFFF0ull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)");
+        c->stat_reruns++;
+        int rc = ensure_pairs(c, (size_t)(total + total / 8 + 1024));
+        if (rc) return rc;
+        c->stat_entries = total;
+        rc = run_draw(c, c->pending_args, false);
+        if (rc) return rc;
+        c->pending = true;
+    }
+    return GS4D_OK;
+}
+
+int touches_pending(gs4d_ctx* c, gs4d_buf b) { return c->pending && (c->pending_args.data == b || c->pending_args.order == b); }
+
+int materialise_fb(gs4d_ctx* c) {
+    if (c->fb_is_clear) { HIPCHK(c, launch_fill(c->st, c->fb, (size_t)c->W * c->H, c->clear)); c->fb_is_clear = false; }
+    return GS4D_OK;
+}
+
+int alloc_fb(gs4d_ctx* c, int w, int h) {
+    if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return fail(c, GS4D_E_INVALID, "framebuffer size must be 1..65535");
+    if (c->fb) { HIPCHK(c, hipStreamSynchronize(c->st)); (void)hipFree(c->fb); c->fb = nullptr; }
+    HIPCHK(c, hipMalloc(&c->fb, (size_t)w * h * 16));
+    c->W = w; c->H = h; c->tiles_x = (w + TILE - 1) / TILE; c->tiles_y = (h + TILE - 1) / TILE;
+    c->fb_is_clear = true;
+    return GS4D_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* gs4d_version(void) { return "gs4d 0.1 (gfx950)"; }
+
+const char* gs4d_last_error(gs4d_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
+    if (!out) return fail(nullptr, GS4D_E_INVALID, "gs4d_create: out == NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(nullptr, GS4D_E_DEVICE, "gs4d_create: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(nullptr, GS4D_E_INVALID, "gs4d_create: bad device index");
+    if ((e = hipSetDevice(device)) != hipSuccess) return hipfail(nullptr, e, "hipSetDevice");
+    gs4d_ctx* c = new (std::nothrow) gs4d_ctx();
+    if (!c) return fail(nullptr, GS4D_E_NOMEM, "gs4d_create: out of host memory");
+    c->device = device;
+    c->bufs.resize(1);
+    memset(&c->u, 0, sizeof c->u);
+    for (int i = 0; i < 4; ++i) c->u.view[5 * i] = c->u.proj[5 * i] = 1.0f;
+    auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
+    if ((e = hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
+    c->st = c->own_st;
+    if ((e = hipEventCreateWithFlags(&c->pending_ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
+    if ((e = hipHostMalloc((void**)&c->host_total, 16, hipHostMallocDefault)) != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
+    memset(c->host_total, 0, 16);
+    int rc = alloc_fb(c, width, height);
+    if (rc) return bail(rc);
+    *out = c;
+    return GS4D_OK;
+}
+
+void gs4d_destroy(gs4d_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); }
+    if (c->fb) (void)hipFree(c->fb);
+    if (c->proj) (void)hipFree(c->proj);
+    if (c->pair_keys) (void)hipFree(c->pair_keys);
+    if (c->pair_vals) (void)hipFree(c->pair_vals);
+    sort_scratch_free(c->depth_sort); sort_scratch_free(c->pair_sort); bin_scratch_free(c->bin);
+    if (c->host_total) (void)hipHostFree(c->host_total);
+    if (c->pending_ev) (void)hipEventDestroy(c->pending_ev);
+    for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
+    if (c->own_st) (void)hipStreamDestroy(c->own_st);
+    delete c;
+}
+
+int gs4d_resize(gs4d_ctx* c, int width, int height) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = resolve_pending(c); if (rc) return rc;
+    if (width == c->W && height == c->H) return GS4D_OK;
+    return alloc_fb(c, width, height);
+}
+
+// ---- buffers ----
+int gs4d_buffer_create(gs4d_ctx* c, const void* data, size_t bytes, gs4d_buf* out) {
+    if (!c || !out) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    gs4d_buf name = 0;
+    for (size_t i = 1; i < c->bufs.size(); ++i) if (!c->bufs[i].alive && !c->bufs[i].d) { name = (gs4d_buf)i; break; }
+    if (!name) { c->bufs.emplace_back(); name = (gs4d_buf)(c->bufs.size() - 1); }
+    Buffer nb;
+    if (bytes) {
+        HIPCHK(c, hipMalloc(&nb.d, bytes));
+        if (data) { hipError_t e = hipMemcpyAsync(nb.d, data, bytes, hipMemcpyHostToDevice, c->st); if (e == hipSuccess) e = hipStreamSynchronize(c->st); if (e != hipSuccess) { (void)hipFree(nb.d); return hipfail(c, e, "buffer upload"); } }
+    }
+    nb.bytes = bytes; nb.alive = true; nb.version = 1;
+    c->bufs[name] = nb;
+    *out = name;
+    return GS4D_OK;
+}
+
+int gs4d_buffer_subdata(gs4d_ctx* c, gs4d_buf b, size_t offset, const void* data, size_t bytes) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    Buffer* B = getbuf(c, b);
+    if (!B) return fail(c, GS4D_E_INVALID, "buffer_subdata: bad buffer name");
+    if (offset > B->bytes || bytes > B->bytes - offset) return fail(c, GS4D_E_INVALID, "buffer_subdata: range outside the buffer");   // GL_INVALID_VALUE
+    if (!bytes) return GS4D_OK;
+    if (!data) return fail(c, GS4D_E_INVALID, "buffer_subdata: data == NULL");
+    if (touches_pending(c, b)) { int rc = resolve_pending(c); if (rc) return rc; }
+    // the caller keeps ownership of `data` and may reuse it on return (glBufferSubData semantics): copy synchronously
+    HIPCHK(c, hipMemcpyAsync((char*)B->d + offset, data, bytes, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    B->version++;
+    return GS4D_OK;
+}
+
+int gs4d_buffer_read(gs4d_ctx* c, gs4d_buf b, size_t offset, void* out, size_t bytes) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    Buffer* B = getbuf(c, b);
+    if (!B) return fail(c, GS4D_E_INVALID, "buffer_read: bad buffer name");
+    if (offset > B->bytes || bytes > B->bytes - offset || (!out && bytes)) return fail(c, GS4D_E_INVALID, "buffer_read: range outside the buffer");
+    if (!bytes) return GS4D_OK;
+    HIPCHK(c, hipMemcpyAsync(out, (const char*)B->d + offset, bytes, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return GS4D_OK;
+}
+
+int gs4d_buffer_destroy(gs4d_ctx* c, gs4d_buf b) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    Buffer* B = getbuf(c, b);
+    if (!B) return GS4D_OK;                         // 0, unknown or already deleted: silently ignored, like glDeleteBuffers
+    if (touches_pending(c, b)) { int rc = resolve_pending(c); if (rc) return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    if (B->d) (void)hipFree(B->d);
+    if (B->soa) (void)hipFree(B->soa);
+    *B = Buffer();
+    for (auto& s : c->slots) if (s == b) s = 0;     // a deleted buffer is unbound
+    return GS4D_OK;
+}
+
+int gs4d_buffer_device_ptr(gs4d_ctx* c, gs4d_buf b, void** dptr, size_t* bytes) {
+    if (!c) return GS4D_E_INVALID;
+    Buffer* B = getbuf(c, b);
+    if (!B) return fail(c, GS4D_E_INVALID, "buffer_device_ptr: bad buffer name");
+    if (dptr) *dptr = B->d;
+    if (bytes) *bytes = B->bytes;
+    B->version++;                                   // the caller may write through the pointer
+    return GS4D_OK;
+}
+
+int gs4d_bind_storage(gs4d_ctx* c, int slot, gs4d_buf b) {
+    if (!c) return GS4D_E_INVALID;
+    if (slot < 0 || slot >= 8) return fail(c, GS4D_E_INVALID, "bind_storage: slot out of range");
+    if (b != 0 && !getbuf(c, b)) return fail(c, GS4D_E_INVALID, "bind_storage: bad buffer name");
+    c->slots[slot] = b;
+    return GS4D_OK;
+}
+
+// ---- state ----
+int gs4d_set_mode(gs4d_ctx* c, int mode) {
+    if (!c) return GS4D_E_INVALID;
+    if (mode < GS4D_MODE_4D_SORTED || mode > GS4D_MODE_2D) return fail(c, GS4D_E_INVALID, "set_mode: unknown mode");
+    c->mode = mode; return GS4D_OK;
+}
+int gs4d_set_uniform_1f(gs4d_ctx* c, int id, float v) {
+    if (!c) return GS4D_E_INVALID;
+    if (id == GS4D_U_TIME) c->u.time = v; else if (id == GS4D_U_MIN_OPACITY) c->u.min_opacity = v; else return fail(c, GS4D_E_INVALID, "set_uniform_1f: unknown uniform");
+    return GS4D_OK;
+}
+int gs4d_set_uniform_mat4(gs4d_ctx* c, int id, const float m[16]) {
+    if (!c || !m) return GS4D_E_INVALID;
+    if (id == GS4D_U_VIEW) memcpy(c->u.view, m, 64); else if (id == GS4D_U_PROJ) memcpy(c->u.proj, m, 64); else return fail(c, GS4D_E_INVALID, "set_uniform_mat4: unknown uniform");
+    return GS4D_OK;
+}
+int gs4d_set_clear_color(gs4d_ctx* c, const float rgba[4]) {
+    if (!c || !rgba) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (c->fb_is_clear && memcmp(c->clear, rgba, 16) != 0) { int rc = materialise_fb(c); if (rc) return rc; }  // glClearColor does not touch pixels
+    memcpy(c->clear, rgba, 16); return GS4D_OK;
+}
+int gs4d_set_blend(gs4d_ctx* c, int src, int dst) {
+    if (!c) return GS4D_E_INVALID;
+    if (src != GS4D_SRC_ALPHA || dst != GS4D_ONE_MINUS_SRC_ALPHA) return fail(c, GS4D_E_UNSUPPORTED, "set_blend: only (SRC_ALPHA, ONE_MINUS_SRC_ALPHA) is implemented");
+    return GS4D_OK;
+}
+int gs4d_clear(gs4d_ctx* c) {
+    if (!c) return GS4D_E_INVALID;
+    // Whatever a still-unvalidated draw left in the framebuffer is discarded by the clear; its inputs are no longer needed.
+    c->pending = false;
+    c->fb_is_clear = true;
+    return GS4D_OK;
+}
+
+// ---- ordering ----
+int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (n <= 1) return GS4D_OK;
+    Buffer* K = getbuf(c, keys); Buffer* V = getbuf(c, vals);
+    if (!K || !V) return fail(c, GS4D_E_INVALID, "sort_pairs: bad buffer name");
+    if (K == V) return fail(c, GS4D_E_INVALID, "sort_pairs: keys and values must be different buffers");
+    if (n >= 0xFFFFFFFFull || K->bytes < n * 4 || V->bytes < n * 4) return fail(c, GS4D_E_INVALID, "sort_pairs: buffers smaller than n elements");
+    if (touches_pending(c, keys) || touches_pending(c, vals)) { int rc = resolve_pending(c); if (rc) return rc; }
+    StageTimer t(c, GS4D_T_SORT);
+    HIPCHK(c, radix_sort_pairs(c->st, c->depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, 32));
+    K->version++; V->version++;
+    return GS4D_OK;
+}
+
+int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_buf keys, gs4d_buf idx, size_t n, int key_mode) {
+    if (!c || !cam) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    Buffer* D = getbuf(c, data); Buffer* K = getbuf(c, keys); Buffer* I = getbuf(c, idx);
+    if (!D || !K || !I) return fail(c, GS4D_E_INVALID, "keygen: bad buffer name");
+    if (key_mode != GS4D_KEY_REF_INV_EUCLID && key_mode != GS4D_KEY_VIEW_Z) return fail(c, GS4D_E_INVALID, "keygen: unknown key mode");
+    if (n >= 0xFFFFFFFFull || D->bytes < n * 96 || K->bytes < n * 4 || I->bytes < n * 4) return fail(c, GS4D_E_INVALID, "keygen: buffers smaller than n elements");
+    if (n == 0) return GS4D_OK;
+    if (touches_pending(c, keys) || touches_pending(c, idx)) { int rc = resolve_pending(c); if (rc) return rc; }
+    int rc = ensure_soa(c, *D); if (rc) return rc;
+    StageTimer tm(c, GS4D_T_KEYGEN);
+    HIPCHK(c, launch_keygen(c->st, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d));
+    K->version++; I->version++;
+    return GS4D_OK;
+}
+
+// ---- draw ----
+static int draw_common(gs4d_ctx* c, DrawArgs& a) {
+    (void)hipSetDevice(c->device);
+    int rc = resolve_pending(c); if (rc) return rc;
+    Buffer* d = getbuf(c, a.data); Buffer* o = getbuf(c, a.order);
+    a.data_version = d ? d->version : 0; a.order_version = o ? o->version : 0;
+    a.fb_was_clear = c->fb_is_clear;
+    const size_t before = c->proj_n;
+    c->proj_n = 0;
+    rc = run_draw(c, a, true);
+    if (rc) { c->proj_n = before; return rc; }
+    if (c->proj_n) { c->pending = true; c->pending_args = a; c->fb_is_clear = false; }   // proj_n != 0 <=> raster work was enqueued
+    if (c->profiling && c->prof_frame < gs4d_ctx::PROF_FRAMES) c->prof_frame++;
+    return GS4D_OK;
+}
+
+int gs4d_draw_instanced(gs4d_ctx* c, size_t instances) {
+    if (!c) return GS4D_E_INVALID;
+    DrawArgs a; a.mode = c->mode; a.u = c->u; a.instances = instances; a.quads = false;
+    if (c->mode == GS4D_MODE_4D_SORTED) { a.data = c->slots[2]; a.order = c->slots[1]; }
+    else if (c->mode == GS4D_MODE_4D_DIRECT || c->mode == GS4D_MODE_2D) { a.data = c->slots[1]; a.order = 0; }
+    else return fail(c, GS4D_E_INVALID, "draw_instanced: GS4D_MODE_3D_FULL draws with gs4d_draw_quads");
+    return draw_common(c, a);
+}
+
+int gs4d_draw_quads(gs4d_ctx* c, gs4d_buf vertices, size_t nquads) {
+    if (!c) return GS4D_E_INVALID;
+    if (c->mode != GS4D_MODE_3D_FULL) return fail(c, GS4D_E_INVALID, "draw_quads: mode must be GS4D_MODE_3D_FULL");
+    DrawArgs a; a.mode = c->mode; a.u = c->u; a.instances = nquads; a.quads = true; a.data = vertices; a.order = 0;
+    return draw_common(c, a);
+}
+
+// ---- read-back ----
+int gs4d_finish(gs4d_ctx* c) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = resolve_pending(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return GS4D_OK;
+}
+
+int gs4d_read_pixels(gs4d_ctx* c, float* rgba, size_t bytes) {
+    if (!c || !rgba) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels: bytes != width*height*16");
+    int rc = resolve_pending(c); if (rc) return rc;
+    rc = materialise_fb(c); if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(rgba, c->fb, bytes, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    return GS4D_OK;
+}
+
+int gs4d_read_pixels_device(gs4d_ctx* c, void* dptr, size_t bytes) {
+    if (!c || !dptr) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels_device: bytes != width*height*16");
+    int rc = resolve_pending(c); if (rc) return rc;
+    rc = materialise_fb(c); if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(dptr, c->fb, bytes, hipMemcpyDeviceToDevice, c->st));
+    return GS4D_OK;
+}
+
+int gs4d_read_pixels_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
+    if (!c || !dptr) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_pixels_rgba8_device: bytes != width*height*4");
+    int rc = resolve_pending(c); if (rc) return rc;
+    rc = materialise_fb(c); if (rc) return rc;
+    HIPCHK(c, launch_pack_rgba8(c->st, c->fb, (size_t)c->W * c->H, (uint32_t*)dptr));
+    return GS4D_OK;
+}
+
+int gs4d_set_stream(gs4d_ctx* c, void* hip_stream) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = resolve_pending(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->st));          // everything queued so far completes before work moves to the other stream
+    c->st = hip_stream ? (hipStream_t)hip_stream : c->own_st;
+    return GS4D_OK;
+}
+
+// ---- measurement / test hooks ----
+int gs4d_set_profiling(gs4d_ctx* c, int on) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (on && c->ev0.empty()) {
+        const size_t n = (size_t)gs4d_ctx::PROF_FRAMES * GS4D_T_COUNT;
+        c->ev0.assign(n, nullptr); c->ev1.assign(n, nullptr); c->ran.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) { HIPCHK(c, hipEventCreate(&c->ev0[i])); HIPCHK(c, hipEventCreate(&c->ev1[i])); }
+    }
+    c->profiling = on != 0;
+    c->prof_frame = 0;
+    std::fill(c->ran.begin(), c->ran.end(), 0);
+    return GS4D_OK;
+}
+
+int gs4d_get_timings(gs4d_ctx* c, float ms[GS4D_T_COUNT]) {
+    if (!c || !ms) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = resolve_pending(c); if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    // average per stage over the frames recorded since profiling was switched on (or since the last call); then restart
+    for (int i = 0; i < GS4D_T_COUNT; ++i) {
+        double sum = 0; int cnt = 0;
+        for (int f = 0; f < gs4d_ctx::PROF_FRAMES && !c->ran.empty(); ++f) {
+            const int slot = f * GS4D_T_COUNT + i;
+            if (!c->ran[slot]) continue;
+            float t = 0;
+            if (hipEventElapsedTime(&t, c->ev0[slot], c->ev1[slot]) == hipSuccess) { sum += t; ++cnt; }
+        }
+        ms[i] = cnt ? (float)(sum / cnt) : -1.0f;
+    }
+    c->prof_frame = 0;
+    std::fill(c->ran.begin(), c->ran.end(), 0);
+    return GS4D_OK;
+}
+
+int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[4]) {
+    if (!c || !stats) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = resolve_pending(c); if (rc) return rc;
+    stats[0] = c->stat_entries; stats[1] = c->pair_cap; stats[2] = c->stat_reruns; stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
+    return GS4D_OK;
+}
+
+int gs4d_debug_read_projected(gs4d_ctx* c, float* out16, size_t nrecords) {
+    if (!c || !out16) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (nrecords > c->proj_n) return fail(c, GS4D_E_INVALID, "debug_read_projected: more records than the last draw projected");
+    int rc = resolve_pending(c); if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(out16, c->proj, nrecords * 64, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    // expose the layout documented in gs4d.h: cx,cy,a0x,a0y,a1x,a1y,alpha,r,g,b,rect0,rect1,hx,hy,valid,0  (already the storage order)
+    return GS4D_OK;
+}
+
+} // extern "C"

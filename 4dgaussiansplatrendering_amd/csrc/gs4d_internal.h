@@ -1,0 +1,65 @@
+// gs4d_internal.h — shared declarations of libgs4d.so's translation units (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/gs4d.h"
+
+namespace gs4d {
+
+constexpr int TILE = 8;             // 8x8-pixel tiles: one wave64 composites one tile
+constexpr int PROJ_FLOATS = 16;     // projected record: 64 B, one aligned segment per splat
+
+// Projected record layout (float4 A,B,C,D), written by preprocess, gathered by binning/composite.
+//  A = cx, cy, a0x, a0y      B = a1x, a1y, alpha, r      C = g, b, rect0 (x0 | y0<<16), rect1 (x1 | y1<<16)   [pixel rect, inclusive]
+//  D = hx, hy, valid(1/0), 0
+// rect0 > rect1 in x (x0 = 1, x1 = 0) marks "no coverage".
+
+struct Uniforms {
+    float view[16];
+    float proj[16];
+    float time;
+    float min_opacity;
+};
+
+// ---- sort.hip ----
+struct SortScratch {
+    uint32_t* keys2 = nullptr; uint32_t* vals2 = nullptr; size_t cap = 0;   // ping-pong buffers (radix_sort.hpp:192-216 scratch)
+    uint32_t* hist = nullptr; size_t hist_cap = 0;                          // [256][nblocks]
+    uint32_t* totals = nullptr;                                             // [256]
+};
+hipError_t sort_scratch_reserve(SortScratch& s, size_t n);
+void sort_scratch_free(SortScratch& s);
+// Stable LSD radix sort of (key,val) pairs on bits [0, key_bits).  n_dev == nullptr: n is exact.  Otherwise the element
+// count is read on the device from *n_dev (<= n, n is the launch capacity); the result always lands back in keys/vals.
+hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits);
+hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx);
+
+// ---- preprocess.hip ----
+hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* 6 planes of n float4 */);
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& u, int W, int H, float4* proj);
+hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, float4* proj);
+hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, float4* proj);
+
+// ---- binning.hip ----
+struct BinScratch {
+    uint32_t* block_sums = nullptr; size_t block_cap = 0;
+    uint32_t* total = nullptr;        // [0] = number of tile-list entries, [1] = overflow flag
+    uint32_t* ranges = nullptr; size_t tiles_cap = 0;   // [2*ntiles] start,end
+};
+hipError_t bin_scratch_reserve(BinScratch& b, size_t ninst, size_t ntiles);
+void bin_scratch_free(BinScratch& b);
+// order == nullptr: instance k draws record k
+hipError_t launch_binning(hipStream_t st, BinScratch& b, const float4* proj, const uint32_t* order, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
+                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap);
+hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pair_keys, size_t pair_cap, size_t ntiles);
+
+// ---- composite.hip ----
+hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, const uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
+                            int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb);
+hipError_t launch_fill(hipStream_t st, float4* fb, size_t npix, const float clear[4]);
+hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, size_t npix, uint32_t* out);
+
+} // namespace gs4d

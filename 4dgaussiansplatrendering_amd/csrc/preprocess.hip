@@ -1,0 +1,240 @@
+// preprocess.hip — per-splat vertex stage: 4D->3D time conditioning, EWA projection, 2x2 eigen-decomposition,
+// window-space quad set-up.  One thread per splat, coalesced float4 loads from SoA planes, one 64-B projected
+// record out.  Replaces the vertex shaders the reference runs 4x per splat (once per quad corner):
+//   Shader/Splats4D/Splat4DVertexShaderInstanced.GLSL:81-150 (and ...Mod.GLSL:61-130)
+//   Shader/Splats3D/Splat3DVertexShaderFull.GLSL:43-98
+//   Shader/Splats2D/Splat2DVSI.GLSL:59-94
+//
+// Compiled with -ffp-contract=off and hipcc's default IEEE divide/sqrt: everything that decides pixel coverage
+// (cx, cy, a0, a1) is bit-identical to the CPU checker, which evaluates the same expressions in the same order.
+#include "gs4d_internal.h"
+
+namespace gs4d {
+
+// AoS 96-B SplatData (Scenes.h:22-37) -> 6 planes of float4: pos, col, sig[0], sig[1], sig[2], sig[3]
+__global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ soa) {
+    // one wave moves 64 records = 384 float4, read fully coalesced, written as 6 x 64 contiguous float4
+    __shared__ float4 stage[4][384];
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    const uint32_t rec0 = (blockIdx.x * 4u + w) * 64u;
+    const uint32_t nrec = rec0 < n ? min(64u, n - rec0) : 0u;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        uint32_t f = j * 64u + lane;
+        if (f < nrec * 6u) stage[w][f] = aos[(size_t)rec0 * 6u + f];
+    }
+    __syncthreads();
+    if (lane < nrec) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) soa[(size_t)p * n + rec0 + lane] = stage[w][lane * 6u + p];
+    }
+}
+
+hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa) {
+    if (n == 0) return hipSuccess;
+    k_soa_repack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa);
+    return hipGetLastError();
+}
+
+// ---- shared device math (same expression order as the checker) ----------------------------------
+struct PU { float V[16]; float P[16]; float time, min_opacity; int W, H; };
+
+__device__ __forceinline__ float maxf_glsl(float a, float b) { return a >= b ? a : b; }
+__device__ __forceinline__ void normalize2(float& x, float& y) { float tx = x * x, ty = y * y; float s = 1.0f / sqrtf(tx + ty); x = x * s; y = y * s; }
+
+struct Quad { float e0x, e0y, e1x, e1y, s0, s1; };   // R columns and the S diagonal used in R*S
+
+// GetEigenValues2x2 / GetEigenVectors2x2 / normalize (…Instanced.GLSL:59-78, 132-138)
+__device__ __forceinline__ void eigen2(float u00, float u01, float u10, float u11, bool guard, float& lx, float& ly, Quad& q) {
+    float m = (u00 + u11) * 0.5f;
+    float p = (u00 * u11) - (u01 * u10);
+    float d = sqrtf((m * m) - p);
+    lx = maxf_glsl(m - d, 0.000001f);
+    ly = maxf_glsl(m + d, 0.000001f);
+    float ax, ay, bx, by;
+    if (guard && u01 == 0.0f) { ax = 1.0f; ay = 0.0f; bx = 0.0f; by = 1.0f; }
+    else {
+        ax = u01; ay = lx - u00;
+        normalize2(ax, ay);
+        bx = ay; by = -ax;
+        normalize2(ax, ay); normalize2(bx, by);
+    }
+    normalize2(ax, ay); normalize2(bx, by);
+    q.e0x = ax; q.e0y = ay; q.e1x = bx; q.e1y = by;
+}
+
+__device__ __forceinline__ bool fin(float x) { return isfinite(x); }
+
+// Window-space set-up + record store.  ncx,ncy = NDC centre; kx,ky = NDC scale of the quad offset.
+__device__ __forceinline__ void emit(float4* __restrict__ proj, uint32_t i, bool valid, const Quad& q, float ncx, float ncy, float kx, float ky,
+                                     int W, int H, float r, float g, float b, float alpha) {
+    float cx = 0, cy = 0, a0x = 0, a0y = 0, a1x = 0, a1y = 0, hx = 0, hy = 0;
+    uint32_t rect0 = 1u, rect1 = 0u;           // empty
+    if (valid) {
+        float hw = (float)W * 0.5f, hh = (float)H * 0.5f;
+        float sx = kx * hw, sy = ky * hh;
+        cx = fmaf(ncx, hw, hw);
+        cy = fmaf(ncy, hh, hh);
+        float r0 = 1.0f / q.s0, r1 = 1.0f / q.s1;
+        a0x = (q.e0x * r0) / sx; a0y = (q.e0y * r0) / sy;
+        a1x = (q.e1x * r1) / sx; a1y = (q.e1y * r1) / sy;
+        hx = 0.5f * (fabsf(q.e0x) * q.s0 + fabsf(q.e1x) * q.s1) * fabsf(sx);
+        hy = 0.5f * (fabsf(q.e0y) * q.s0 + fabsf(q.e1y) * q.s1) * fabsf(sy);
+        valid = fin(cx) && fin(cy) && fin(a0x) && fin(a0y) && fin(a1x) && fin(a1y) && fin(hx) && fin(hy) && fin(alpha);
+        if (valid) {
+            // conservative pixel rectangle: candidates are pixels whose centre lies within the bbox grown by a margin that
+            // dominates the rounding of the coverage predicate
+            float mx = 0.01f + 1e-5f * hx, my = 0.01f + 1e-5f * hy;
+            float fx0 = ceilf(cx - hx - mx - 0.5f), fx1 = floorf(cx + hx + mx - 0.5f);
+            float fy0 = ceilf(cy - hy - my - 0.5f), fy1 = floorf(cy + hy + my - 0.5f);
+            fx0 = fmaxf(fx0, 0.0f); fy0 = fmaxf(fy0, 0.0f);
+            fx1 = fminf(fx1, (float)(W - 1)); fy1 = fminf(fy1, (float)(H - 1));
+            if (fx0 <= fx1 && fy0 <= fy1) {
+                rect0 = (uint32_t)fx0 | ((uint32_t)fy0 << 16);
+                rect1 = (uint32_t)fx1 | ((uint32_t)fy1 << 16);
+            }
+        }
+    }
+    if (!valid) { cx = cy = a0x = a0y = a1x = a1y = hx = hy = 0.0f; alpha = 0.0f; rect0 = 1u; rect1 = 0u; }
+    float4* o = proj + (size_t)i * 4;
+    o[0] = make_float4(cx, cy, a0x, a0y);
+    o[1] = make_float4(a1x, a1y, alpha, r);
+    o[2] = make_float4(g, b, __uint_as_float(rect0), __uint_as_float(rect1));
+    o[3] = make_float4(hx, hy, valid ? 1.0f : 0.0f, 0.0f);
+}
+
+// …Instanced.GLSL:97-147 == Splat3DVertexShaderFull.GLSL:45-95.  C[c][r] = 3x3 covariance.
+__device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float mz, const float C[3][3], Quad& q, float& ncx, float& ncy) {
+    const float* V = u.V; const float* P = u.P;
+    float pcx = ((V[0] * mx + V[4] * my) + V[8] * mz) + V[12] * 1.0f;
+    float pcy = ((V[1] * mx + V[5] * my) + V[9] * mz) + V[13] * 1.0f;
+    float pcz = ((V[2] * mx + V[6] * my) + V[10] * mz) + V[14] * 1.0f;
+    float pcw = ((V[3] * mx + V[7] * my) + V[11] * mz) + V[15] * 1.0f;
+    float psx = ((P[0] * pcx + P[4] * pcy) + P[8] * pcz) + P[12] * pcw;
+    float psy = ((P[1] * pcx + P[5] * pcy) + P[9] * pcz) + P[13] * pcw;
+    float psz = ((P[2] * pcx + P[6] * pcy) + P[10] * pcz) + P[14] * pcw;
+    float psw = ((P[3] * pcx + P[7] * pcy) + P[11] * pcz) + P[15] * pcw;
+    float rw = 1.0f / psw;
+    psx = rw * psx; psy = rw * psy; psz = rw * psz; psw = rw * psw;
+    float z = psz / psw;
+    float bound = 1.2f * psw;
+    if (z < 0.0f || z > 1.0f || psx < -bound || psx > bound || psy < -bound || psy > bound) return false;
+    if (!(fin(psx) && fin(psy) && fin(z))) return false;
+    float z2 = pcz * pcz;
+    float J[3][3] = { { 1.0f / pcz, 0.0f, -pcx / z2 }, { 0.0f, 1.0f / pcz, -pcy / z2 }, { 0.0f, 0.0f, 0.0f } };
+    float Wt[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Wt[c][r] = V[4 * r + c];
+    float T[3][3], Tt[3][3], A[3][3], cov[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) T[c][r] = Wt[0][r] * J[c][0] + Wt[1][r] * J[c][1] + Wt[2][r] * J[c][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) Tt[c][r] = T[r][c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) A[c][r] = Tt[0][r] * C[c][0] + Tt[1][r] * C[c][1] + Tt[2][r] * C[c][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) cov[c][r] = A[0][r] * T[c][0] + A[1][r] * T[c][1] + A[2][r] * T[c][2];
+    float lx, ly;
+    eigen2(cov[0][0], cov[0][1], cov[1][0], cov[1][1], false, lx, ly, q);
+    q.s0 = sqrtf(lx); q.s1 = sqrtf(ly);
+    ncx = psx; ncy = psy;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict__ soa, uint32_t n, PU u, float4* __restrict__ proj) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 pos = soa[i], col = soa[(size_t)n + i];
+    const float4 s0 = soa[(size_t)2 * n + i], s1 = soa[(size_t)3 * n + i], s2 = soa[(size_t)4 * n + i], s3 = soa[(size_t)5 * n + i];
+    float s44 = s3.w;
+    float dt = u.time - pos.w;
+    float ot = maxf_glsl(expf(-0.5f * dt * (1.0f / s44) * dt), u.min_opacity);     // :48-51, 83
+    float ax = s0.w, ay = s1.w, az = s2.w;                                       // iSig[0][3], [1][3], [2][3]
+    float k = (1.0f / s44) * dt;
+    float mx = pos.x + k * ax, my = pos.y + k * ay, mz = pos.z + k * az;         // :86
+    float inv = 1.0f / s44;
+    float tv[3] = { inv * s3.x, inv * s3.y, inv * s3.z };                        // :87
+    float a[3] = { ax, ay, az };
+    float S[3][3] = { { s0.x, s0.y, s0.z }, { s1.x, s1.y, s1.z }, { s2.x, s2.y, s2.z } };
+    float C[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) C[c][r] = S[c][r] - a[r] * tv[c];              // :89-95
+    Quad q; float ncx = 0, ncy = 0;
+    bool valid = project3d(u, mx, my, mz, C, q, ncx, ncy);
+    emit(proj, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w);
+}
+
+__global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__ verts, uint32_t n, PU u, float4* __restrict__ proj) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float* v = verts + (size_t)72 * i;      // vertex 0 of the quad: {vpos2, spos3, col4, sig9}
+    float C[3][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) C[c][r] = v[9 + 3 * c + r];
+    Quad q; float ncx = 0, ncy = 0;
+    bool valid = project3d(u, v[2], v[3], v[4], C, q, ncx, ncy);
+    emit(proj, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8]);
+}
+
+__global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__ recs, uint32_t n, PU u, float4* __restrict__ proj) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float* rec = recs + (size_t)12 * i;
+    const float* P = u.P;
+    float x = rec[0], y = rec[1];
+    float psx = ((P[0] * x + P[4] * y) + P[8] * -1.0f) + P[12] * 1.0f;             // Splat2DVSI.GLSL:64
+    float psy = ((P[1] * x + P[5] * y) + P[9] * -1.0f) + P[13] * 1.0f;
+    float psz = ((P[2] * x + P[6] * y) + P[10] * -1.0f) + P[14] * 1.0f;
+    float psw = ((P[3] * x + P[7] * y) + P[11] * -1.0f) + P[15] * 1.0f;
+    float rw = 1.0f / psw;
+    psx = rw * psx; psy = rw * psy; psz = rw * psz; psw = rw * psw;
+    Quad q; float lx, ly;
+    eigen2(rec[8], rec[9], rec[10], rec[11], true, lx, ly, q);
+    float l0 = sqrtf(lx * 2.0f), l1 = sqrtf(ly * 2.0f);                           // :68-69
+    q.s0 = l1; q.s1 = l0;                                                         // S = mat2(l1,0,0,l0) :76
+    float zc = -5.0f + psz, wc4 = 1.0f + psw;
+    float clipw = P[11] * zc + P[15] * wc4;
+    float clipz = P[10] * zc + P[14] * wc4;
+    bool valid = (clipw > 0.0f) && !(clipz < -clipw || clipz > clipw);
+    float kx = P[0] / clipw, ky = P[5] / clipw;
+    emit(proj, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
+}
+
+static PU make_pu(const Uniforms& un, int W, int H) {
+    PU u;
+    for (int i = 0; i < 16; ++i) { u.V[i] = un.view[i]; u.P[i] = un.proj[i]; }
+    u.time = un.time; u.min_opacity = un.min_opacity; u.W = W; u.H = H;
+    return u;
+}
+
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, float4* proj) {
+    if (n == 0) return hipSuccess;
+    k_preprocess_4d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(soa, (uint32_t)n, make_pu(un, W, H), proj);
+    return hipGetLastError();
+}
+hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, float4* proj) {
+    if (n == 0) return hipSuccess;
+    k_preprocess_3d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(verts72, (uint32_t)n, make_pu(un, W, H), proj);
+    return hipGetLastError();
+}
+hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, float4* proj) {
+    if (n == 0) return hipSuccess;
+    k_preprocess_2d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(rec48, (uint32_t)n, make_pu(un, W, H), proj);
+    return hipGetLastError();
+}
+
+} // namespace gs4d

@@ -1,0 +1,184 @@
+// gs4d_host.cpp — host-side (CPU) half of the path: the splat parameterisation and camera matrices the
+// reference computes with GLM before anything reaches the GPU.  Part of libgs4d.so so that callers without
+// GLM (the Python binding, the C++ scene driver) can build SSBO contents that are bit-identical to the
+// reference's.  Pinned by tests/golden/* (generated from the reference's own code).
+//
+//   Splat4D::Splat4D (rot,scale,lifetime,fade,dir)   4DSplatRendering/Splat.h:132-159
+//   Splat4D::Splat4D (rot0,rot1,scalar)              4DSplatRendering/Splat.h:91-130
+//   Splat3D::Splat3D                                 4DSplatRendering/Splat.h:334-344
+//   Camera::GetViewMatrix / GetProjMatrix            4DSplatRendering/Camera.cpp:50-58
+//   orientation of teapot splats                     4DSplatRendering/Scenes.h:268
+//   SplatData record layout                          4DSplatRendering/Scenes.h:22-37
+// GLM 0.9.9.9 evaluation order is reproduced (float32, no contraction: build with -ffp-contract=off).
+#include "../../include/gs4d.h"
+#include <cmath>
+#include <cstring>
+
+namespace {
+
+// column-major fixed-size matrices, element (col c, row r) = a[c*N + r]
+template <int N> struct Mat { float a[N * N]; float& at(int c, int r) { return a[c * N + r]; } float at(int c, int r) const { return a[c * N + r]; } };
+using Mat3 = Mat<3>;
+using Mat4 = Mat<4>;
+struct Vec3 { float x, y, z; };
+struct Q { float w, x, y, z; };
+
+inline Vec3 sub(Vec3 a, Vec3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+inline float dot(Vec3 a, Vec3 b) { const float p0 = a.x * b.x, p1 = a.y * b.y, p2 = a.z * b.z; return p0 + p1 + p2; }
+inline Vec3 cross(Vec3 a, Vec3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+inline Vec3 scale(Vec3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+inline Vec3 unit(Vec3 a) { return scale(a, 1.0f / std::sqrt(dot(a, a))); }
+
+// mat3 product, element = ((a0*b0) + (a1*b1)) + (a2*b2)
+Mat3 mm(const Mat3& A, const Mat3& B) {
+    Mat3 R;
+    for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) R.at(c, r) = A.at(0, r) * B.at(c, 0) + A.at(1, r) * B.at(c, 1) + A.at(2, r) * B.at(c, 2);
+    return R;
+}
+Mat3 tr(const Mat3& A) { Mat3 R; for (int c = 0; c < 3; ++c) for (int r = 0; r < 3; ++r) R.at(c, r) = A.at(r, c); return R; }
+Mat4 mm(const Mat4& A, const Mat4& B) {
+    Mat4 R;
+    for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r)
+        R.at(c, r) = ((A.at(0, r) * B.at(c, 0) + A.at(1, r) * B.at(c, 1)) + A.at(2, r) * B.at(c, 2)) + A.at(3, r) * B.at(c, 3);
+    return R;
+}
+Mat4 tr(const Mat4& A) { Mat4 R; for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) R.at(c, r) = A.at(r, c); return R; }
+
+Mat3 rot_of(Q q) {   // glm::mat3_cast
+    const float xx = q.x * q.x, yy = q.y * q.y, zz = q.z * q.z, xz = q.x * q.z, xy = q.x * q.y, yz = q.y * q.z, wx = q.w * q.x, wy = q.w * q.y, wz = q.w * q.z;
+    Mat3 R;
+    R.at(0, 0) = 1.0f - 2.0f * (yy + zz); R.at(0, 1) = 2.0f * (xy + wz);        R.at(0, 2) = 2.0f * (xz - wy);
+    R.at(1, 0) = 2.0f * (xy - wz);        R.at(1, 1) = 1.0f - 2.0f * (xx + zz); R.at(1, 2) = 2.0f * (yz + wx);
+    R.at(2, 0) = 2.0f * (xz + wy);        R.at(2, 1) = 2.0f * (yz - wx);        R.at(2, 2) = 1.0f - 2.0f * (xx + yy);
+    return R;
+}
+
+Q unit(Q q) {        // glm::normalize(quat)
+    const float a = q.w * q.w, b = q.x * q.x, c = q.y * q.y, d = q.z * q.z;
+    const float len = std::sqrt((a + b) + (c + d));
+    if (len <= 0.0f) return { 1.0f, 0.0f, 0.0f, 0.0f };
+    const float inv = 1.0f / len;
+    return { q.w * inv, q.x * inv, q.y * inv, q.z * inv };
+}
+
+Q quat_of(const Mat3& m) {   // glm::quat_cast
+    const float tx = m.at(0, 0) - m.at(1, 1) - m.at(2, 2);
+    const float ty = m.at(1, 1) - m.at(0, 0) - m.at(2, 2);
+    const float tz = m.at(2, 2) - m.at(0, 0) - m.at(1, 1);
+    const float tw = m.at(0, 0) + m.at(1, 1) + m.at(2, 2);
+    int which = 0; float best = tw;
+    if (tx > best) { best = tx; which = 1; }
+    if (ty > best) { best = ty; which = 2; }
+    if (tz > best) { best = tz; which = 3; }
+    const float big = std::sqrt(best + 1.0f) * 0.5f;
+    const float k = 0.25f / big;
+    if (which == 0) return { big, (m.at(1, 2) - m.at(2, 1)) * k, (m.at(2, 0) - m.at(0, 2)) * k, (m.at(0, 1) - m.at(1, 0)) * k };
+    if (which == 1) return { (m.at(1, 2) - m.at(2, 1)) * k, big, (m.at(0, 1) + m.at(1, 0)) * k, (m.at(2, 0) + m.at(0, 2)) * k };
+    if (which == 2) return { (m.at(2, 0) - m.at(0, 2)) * k, (m.at(0, 1) + m.at(1, 0)) * k, big, (m.at(1, 2) + m.at(2, 1)) * k };
+    return { (m.at(0, 1) - m.at(1, 0)) * k, (m.at(2, 0) + m.at(0, 2)) * k, (m.at(1, 2) + m.at(2, 1)) * k, big };
+}
+
+Mat3 sigma3(Q q, const float s[3]) {     // R * S * S * transpose(R), left to right
+    Mat3 S; std::memset(&S, 0, sizeof S); S.at(0, 0) = s[0]; S.at(1, 1) = s[1]; S.at(2, 2) = s[2];
+    const Mat3 R = rot_of(q);
+    return mm(mm(mm(R, S), S), tr(R));
+}
+
+} // namespace
+
+extern "C" {
+
+void gs4d_host_look_at(const float eye[3], const float orientation[3], const float up[3], float view[16]) {
+    const Vec3 e = { eye[0], eye[1], eye[2] };
+    const Vec3 centre = { eye[0] + orientation[0], eye[1] + orientation[1], eye[2] + orientation[2] };
+    const Vec3 f = unit(sub(centre, e));
+    const Vec3 s = unit(cross(f, { up[0], up[1], up[2] }));
+    const Vec3 u = cross(s, f);
+    const float m[16] = { s.x, u.x, -f.x, 0.0f, s.y, u.y, -f.y, 0.0f, s.z, u.z, -f.z, 0.0f, -dot(s, e), -dot(u, e), dot(f, e), 1.0f };
+    std::memcpy(view, m, sizeof m);
+}
+
+void gs4d_host_perspective(float fov_deg, int width, int height, float znear, float zfar, float proj[16]) {
+    const float fovy = fov_deg * 0.01745329251994329576923690768489f;
+    const float aspect = (float)width / (float)height;
+    const float th = std::tan(fovy / 2.0f);
+    float m[16] = { 0 };
+    m[0] = 1.0f / (aspect * th);
+    m[5] = 1.0f / th;
+    m[10] = -(zfar + znear) / (zfar - znear);
+    m[11] = -1.0f;
+    m[14] = -(2.0f * zfar * znear) / (zfar - znear);
+    std::memcpy(proj, m, sizeof m);
+}
+
+void gs4d_host_quat_look_at(const float dir[3], const float up[3], float q_wxyz[4]) {
+    const Vec3 d = unit(Vec3{ dir[0], dir[1], dir[2] });
+    const Vec3 back = { -d.x, -d.y, -d.z };
+    const Vec3 right = cross({ up[0], up[1], up[2] }, back);
+    const Vec3 c0 = scale(right, 1.0f / std::sqrt(std::fmax(0.00001f, dot(right, right))));
+    const Vec3 c1 = cross(back, c0);
+    Mat3 B;
+    B.at(0, 0) = c0.x; B.at(0, 1) = c0.y; B.at(0, 2) = c0.z;
+    B.at(1, 0) = c1.x; B.at(1, 1) = c1.y; B.at(1, 2) = c1.z;
+    B.at(2, 0) = back.x; B.at(2, 1) = back.y; B.at(2, 2) = back.z;
+    const Q q = unit(quat_of(B));
+    q_wxyz[0] = q.w; q_wxyz[1] = q.x; q_wxyz[2] = q.y; q_wxyz[3] = q.z;
+}
+
+void gs4d_host_splat3d_cov(const float q_wxyz[4], const float scale3[3], float cov9[9]) {
+    const Mat3 g = sigma3({ q_wxyz[0], q_wxyz[1], q_wxyz[2], q_wxyz[3] }, scale3);
+    std::memcpy(cov9, g.a, sizeof g.a);
+}
+
+void gs4d_host_splat4d_cov(const float q_wxyz[4], const float scale3[3], float lifetime, float fade, const float dir[3], float cov16[16]) {
+    // Splat.h:139: `log(fadeof)` on a float is the float overload; the -2.0 factor promotes the quotient to double
+    const double denom = (fade == 0.5f) ? (double)1.3862943611198906f : -2.0 * (double)std::log(fade);
+    const float sd = (float)((double)(lifetime * lifetime) / denom);
+    const float td[3] = { dir[0] * sd, dir[1] * sd, dir[2] * sd };
+    const Mat3 sig = sigma3({ q_wxyz[0], q_wxyz[1], q_wxyz[2], q_wxyz[3] }, scale3);
+    const float inv = 1.0f / sd;
+    Mat4 C;
+    for (int c = 0; c < 3; ++c) {
+        for (int r = 0; r < 3; ++r) C.at(c, r) = sig.at(c, r) + (td[r] * td[c]) * inv;     // sig + (1/s) * outerProduct(td, td)
+        C.at(c, 3) = td[c];
+        C.at(3, c) = td[c];
+    }
+    C.at(3, 3) = sd;
+    std::memcpy(cov16, C.a, sizeof C.a);
+}
+
+void gs4d_host_splat4d_cov2q(const float q0_wxyz[4], const float q1_wxyz[4], const float scale4[4], float cov16[16]) {
+    const Q l = unit(Q{ q0_wxyz[0], q0_wxyz[1], q0_wxyz[2], q0_wxyz[3] });
+    const Q r = unit(Q{ q1_wxyz[0], q1_wxyz[1], q1_wxyz[2], q1_wxyz[3] });
+    const Mat4 L = { { l.w, -l.x, -l.y, -l.z,  l.x, l.w, -l.z, l.y,  l.y, l.z, l.w, -l.x,  l.z, -l.y, l.x, l.w } };
+    const Mat4 R = { { r.w, -r.x, -r.y, -r.z,  r.x, r.w, r.z, -r.y,  r.y, -r.z, r.w, r.x,  r.z, r.y, -r.x, r.w } };
+    Mat4 S; std::memset(&S, 0, sizeof S);
+    for (int i = 0; i < 4; ++i) S.at(i, i) = scale4[i];
+    const Mat4 rot = mm(L, R);
+    const Mat4 g = mm(mm(mm(rot, S), tr(S)), tr(rot));
+    std::memcpy(cov16, g.a, sizeof g.a);
+}
+
+void gs4d_host_build_records_3d(size_t n, const float* pos3, const float* q_wxyz, const float* scale3, const float* rgba, float* rec) {
+    for (size_t i = 0; i < n; ++i) {
+        float* o = rec + 24 * i;
+        float g[9];
+        gs4d_host_splat3d_cov(q_wxyz + 4 * i, scale3 + 3 * i, g);
+        o[0] = pos3[3 * i]; o[1] = pos3[3 * i + 1]; o[2] = pos3[3 * i + 2]; o[3] = 0.0f;         // mu_t = 0
+        std::memcpy(o + 4, rgba + 4 * i, 16);
+        for (int c = 0; c < 3; ++c) { o[8 + 4 * c] = g[3 * c]; o[9 + 4 * c] = g[3 * c + 1]; o[10 + 4 * c] = g[3 * c + 2]; o[11 + 4 * c] = 0.0f; }
+        o[20] = 0.0f; o[21] = 0.0f; o[22] = 0.0f; o[23] = 1.0f;                                 // Sigma44 = 1
+    }
+}
+
+void gs4d_host_build_records_4d(size_t n, const float* pos4, const float* q_wxyz, const float* scale3, const float* lifetime, const float* fade,
+                                const float* dir3, const float* rgba, float* rec) {
+    for (size_t i = 0; i < n; ++i) {
+        float* o = rec + 24 * i;
+        std::memcpy(o, pos4 + 4 * i, 16);
+        std::memcpy(o + 4, rgba + 4 * i, 16);
+        gs4d_host_splat4d_cov(q_wxyz + 4 * i, scale3 + 3 * i, lifetime[i], fade[i], dir3 + 3 * i, o + 8);
+    }
+}
+
+} // extern "C"

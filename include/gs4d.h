@@ -1,0 +1,141 @@
+/* gs4d.h — C ABI of libgs4d.so, the MI355X (gfx950) forward Gaussian-splat rasteriser.
+ *
+ * This is the drop-in boundary for ONE path of EndMy5uffering/4DGaussianSplatRendering: everything
+ * from the upload of the splat SSBO to pixels.  The reference has no FFI of its own:
+ * the surface it exposes to its scenes is a set of C++ classes over OpenGL (Renderer, ShareStorageBuffer,
+ * Shader, radix_sort::sorter) plus six raw GL calls.  Every entry point below names the reference call
+ * it stands in for (file:line relative to the reference tree); the C++ mirror of those classes that a
+ * maintainer would compile Scenes.h against lives in 4dgaussiansplatrendering_amd/host/ and is a thin
+ * wrapper over these functions.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returns 0 on success or a
+ * negative GS4D_E_* code (no exception crosses the ABI); gs4d_last_error() returns a description.
+ * Matrices are 16 floats, column-major (m[4*c + r]), exactly what glUniformMatrix4fv(…, GL_FALSE, …)
+ * receives from glm::mat4.  Buffers are named by small integers like GL buffer names; 0 is "none";
+ * deleting 0 or an already-deleted name is tolerated (the reference double-deletes, Scenes.h:220-224, 291-299).
+ * Calls are issued in order on one HIP stream per context; only the read-back / finish calls block.
+ * One context = one GPU; contexts are independent (one process per GPU for multi-GPU runs).
+ * The framebuffer is RGBA float32, row 0 = bottom row (OpenGL window origin).
+ */
+#ifndef GS4D_H
+#define GS4D_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define GS4D_API __attribute__((visibility("default")))
+#else
+#define GS4D_API
+#endif
+
+typedef struct gs4d_ctx gs4d_ctx;
+typedef uint32_t gs4d_buf;
+
+enum {
+    GS4D_OK = 0,
+    GS4D_E_INVALID = -1,      /* bad argument / bad buffer name / size mismatch          */
+    GS4D_E_DEVICE = -2,       /* HIP runtime error (message in gs4d_last_error)          */
+    GS4D_E_UNSUPPORTED = -3,  /* state the path does not implement (e.g. other blend funcs) */
+    GS4D_E_NOMEM = -4
+};
+
+/* Pipeline selection = which shader pair the reference scene would have bound (Shader::AddShaderSource paths). */
+enum {
+    GS4D_MODE_4D_SORTED = 0, /* Shader/Splats4D/Splat4DVertexShaderInstanced.GLSL + Splat4DFragShader.GLSL: slot 1 = sortidx[], slot 2 = SplatData[] (96 B) */
+    GS4D_MODE_4D_DIRECT = 1, /* Shader/Splats4D/Splat4DVertexShaderMod.GLSL: slot 1 = SplatData[], instance id indexes it directly                         */
+    GS4D_MODE_3D_FULL   = 2, /* Shader/Splats3D/Splat3DVertexShaderFull.GLSL + Splat3DFragShaderFull.GLSL: 4 x 72-B vertices per splat (gs4d_draw_quads) */
+    GS4D_MODE_2D        = 3  /* Shader/Splats2D/Splat2DVSI.GLSL + Splat2DFragShader.GLSL: slot 1 = 48-B records                                         */
+};
+
+enum { GS4D_U_TIME = 0, GS4D_U_MIN_OPACITY = 1 };  /* uTime, uMinOpacity (Scenes.h:331-332) */
+enum { GS4D_U_VIEW = 0, GS4D_U_PROJ = 1 };         /* uView, uProj       (Scenes.h:333-334) */
+
+enum { GS4D_KEY_REF_INV_EUCLID = 0,  /* 1/|mean'(t) - cam|, the reference's key (Scenes.h:28-36, 314-319) */
+       GS4D_KEY_VIEW_Z = 1 };        /* extra: key = 1/(-z_view) of the time-conditioned mean              */
+
+enum { GS4D_SRC_ALPHA = 0x0302, GS4D_ONE_MINUS_SRC_ALPHA = 0x0303 };  /* GL enum values, Application.cpp:137-138, 150 */
+
+/* Per-stage device timings of the most recent calls, measured with HIP events on the context's stream. */
+enum { GS4D_T_KEYGEN = 0, GS4D_T_SORT = 1, GS4D_T_PREPROCESS = 2, GS4D_T_BINNING = 3, GS4D_T_PAIRSORT = 4, GS4D_T_COMPOSITE = 5, GS4D_T_COUNT = 6 };
+
+/* ---- context (stands in for the GL context + default framebuffer; Application.cpp:89-97, glViewport :69) ---- */
+GS4D_API int  gs4d_create(int device, int width, int height, gs4d_ctx** out);
+GS4D_API void gs4d_destroy(gs4d_ctx* ctx);
+GS4D_API int  gs4d_resize(gs4d_ctx* ctx, int width, int height);                 /* glViewport / Camera::Resize            */
+GS4D_API const char* gs4d_last_error(gs4d_ctx* ctx);                             /* ctx may be NULL: error of a failed create */
+
+/* ---- buffers: glGenBuffers+glBufferData / glBufferStorage (ShareStorageBuffer.cpp:3-8, Scenes.h:241-247),
+ *      glBufferSubData (ShareStorageBuffer.cpp:30-40, Scenes.h:321-325), glDeleteBuffers (ShareStorageBuffer.cpp:10-13) ---- */
+GS4D_API int gs4d_buffer_create(gs4d_ctx* ctx, const void* data /* may be NULL */, size_t bytes, gs4d_buf* out);
+GS4D_API int gs4d_buffer_subdata(gs4d_ctx* ctx, gs4d_buf buf, size_t offset, const void* data, size_t bytes);
+GS4D_API int gs4d_buffer_read(gs4d_ctx* ctx, gs4d_buf buf, size_t offset, void* out, size_t bytes);  /* blocking; no reference counterpart (tests/tools) */
+GS4D_API int gs4d_buffer_destroy(gs4d_ctx* ctx, gs4d_buf buf);
+GS4D_API int gs4d_buffer_device_ptr(gs4d_ctx* ctx, gs4d_buf buf, void** dptr, size_t* bytes);        /* zero-copy interop with a caller that owns HIP memory */
+/* glBindBufferBase(GL_SHADER_STORAGE_BUFFER, slot, buf) (Scenes.h:336, ShareStorageBuffer.cpp:20-23); slots 0..7 */
+GS4D_API int gs4d_bind_storage(gs4d_ctx* ctx, int slot, gs4d_buf buf);
+
+/* ---- pipeline state: Shader::Bind / SetUniform1f / SetUniformMat4f (Shader.cpp:171-174, 206-209), glClearColor
+ *      (Application.cpp:125), glBlendFunc (Application.cpp:150), Renderer::Clear (Renderer.cpp:20-23) ---- */
+GS4D_API int gs4d_set_mode(gs4d_ctx* ctx, int mode);
+GS4D_API int gs4d_set_uniform_1f(gs4d_ctx* ctx, int id, float v);
+GS4D_API int gs4d_set_uniform_mat4(gs4d_ctx* ctx, int id, const float m[16]);
+GS4D_API int gs4d_set_clear_color(gs4d_ctx* ctx, const float rgba[4]);
+GS4D_API int gs4d_set_blend(gs4d_ctx* ctx, int src_factor, int dst_factor);      /* only (SRC_ALPHA, ONE_MINUS_SRC_ALPHA), the reference's default */
+GS4D_API int gs4d_clear(gs4d_ctx* ctx);
+
+/* ---- ordering ---- */
+/* radix_sort::sorter::sort(key_buf, val_buf, n) (radix_sort.hpp:258-392): stable ascending sort of n (uint32 key, uint32 value)
+ * pairs, in place.  Output == std::stable_sort by key; n <= 1 is a no-op (radix_sort.hpp:260). */
+GS4D_API int gs4d_sort_pairs(gs4d_ctx* ctx, gs4d_buf keys, gs4d_buf vals, size_t n);
+/* GPU replacement for the CPU key loop + two glBufferSubData uploads (Scenes.h:314-325): writes keys_f32[i] and idx_u32[i] = i
+ * for the n 96-byte SplatData records in `data`. */
+GS4D_API int gs4d_keygen(gs4d_ctx* ctx, gs4d_buf data, float t, const float cam_pos[3], gs4d_buf keys_f32, gs4d_buf idx_u32, size_t n, int key_mode);
+
+/* ---- draw: Renderer::Draw(va, ib, instances) -> glDrawElementsInstanced(GL_TRIANGLES, 6, …, instances) (Renderer.cpp:33-39)
+ *      with the state set above; blends `instances` quads into the framebuffer in instance order. ---- */
+GS4D_API int gs4d_draw_instanced(gs4d_ctx* ctx, size_t instances);
+/* Renderer::Draw(va, ib) -> glDrawElements on 4 vertices x 72 B per splat (Scenes.h:1690-1692): GS4D_MODE_3D_FULL */
+GS4D_API int gs4d_draw_quads(gs4d_ctx* ctx, gs4d_buf vertices, size_t nquads);
+
+/* ---- read-back (no reference counterpart: the reference never reads its framebuffer) ---- */
+GS4D_API int gs4d_read_pixels(gs4d_ctx* ctx, float* rgba, size_t bytes);          /* blocking; bytes == width*height*16     */
+GS4D_API int gs4d_read_pixels_device(gs4d_ctx* ctx, void* dptr, size_t bytes);    /* device-to-device on the context stream; call gs4d_finish before using dptr on another stream */
+/* Presentation format of the reference's window framebuffer (RGBA8 unorm, Application.cpp:89): clamp to [0,1], round to nearest.
+ * Device-to-device on the context stream, width*height*4 bytes. */
+GS4D_API int gs4d_read_pixels_rgba8_device(gs4d_ctx* ctx, void* dptr, size_t bytes);
+/* Run this context's work on a caller-owned HIP stream (hipStream_t passed as void*; NULL restores the context's own stream).
+ * Lets a host framework order its own work (e.g. an RCCL gather of the frames) after the draw without a host synchronisation. */
+GS4D_API int gs4d_set_stream(gs4d_ctx* ctx, void* hip_stream);
+GS4D_API int gs4d_finish(gs4d_ctx* ctx);                                          /* hipStreamSynchronize                   */
+
+/* ---- measurement / test hooks ---- */
+GS4D_API int gs4d_set_profiling(gs4d_ctx* ctx, int on);
+GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);             /* blocking; -1.0f for stages that did not run */
+GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[4]);                    /* [0] tile-list entries of the last draw, [1] capacity, [2] re-runs after overflow, [3] tiles */
+/* Projected records of the last draw, 16 floats per record in record order:
+ * cx, cy, a0x, a0y, a1x, a1y, alpha, r, g, b, tile-rect (2 words, bit patterns), hx, hy, valid(1/0), 0 */
+GS4D_API int gs4d_debug_read_projected(gs4d_ctx* ctx, float* out16, size_t nrecords);
+
+/* ---- host-side parameterisation (CPU code inside libgs4d.so; mirrors the reference's host math so that a caller
+ *      without GLM can build SSBO contents).  Quaternions are w,x,y,z (GLM 0.9.9.9 order). ---- */
+GS4D_API void gs4d_host_look_at(const float eye[3], const float orientation[3], const float up[3], float view[16]);            /* Camera.cpp:50-53 */
+GS4D_API void gs4d_host_perspective(float fov_deg, int width, int height, float znear, float zfar, float proj[16]);             /* Camera.cpp:55-58 */
+GS4D_API void gs4d_host_quat_look_at(const float dir[3], const float up[3], float q_wxyz[4]);                                   /* Scenes.h:268     */
+GS4D_API void gs4d_host_splat3d_cov(const float q_wxyz[4], const float scale[3], float cov9[9]);                                /* Splat.h:334-344  */
+GS4D_API void gs4d_host_splat4d_cov(const float q_wxyz[4], const float scale[3], float lifetime, float fade, const float dir[3], float cov16[16]); /* Splat.h:132-159 */
+GS4D_API void gs4d_host_splat4d_cov2q(const float q0_wxyz[4], const float q1_wxyz[4], const float scale4[4], float cov16[16]);   /* Splat.h:91-130   */
+/* Batch builders: n splats -> n 96-byte SplatData records (Scenes.h:22-37 layout).
+ * static 3D embedding (Scenes.h:2487 ObjectDisplay): Sigma3 in the upper 3x3, Sigma[i][3]=Sigma[3][i]=0, Sigma44=1, mu_t=0. */
+GS4D_API void gs4d_host_build_records_3d(size_t n, const float* pos3, const float* q_wxyz, const float* scale3, const float* rgba, float* records24);
+GS4D_API void gs4d_host_build_records_4d(size_t n, const float* pos4, const float* q_wxyz, const float* scale3, const float* lifetime, const float* fade,
+                                const float* dir3, const float* rgba, float* records24);
+
+GS4D_API const char* gs4d_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS4D_H */
