@@ -1,0 +1,130 @@
+"""CPU: properties of the oracle's vertex/fragment/blend restatement that follow from the shader text
+(Splat4DVertexShaderInstanced.GLSL, Splat4DFragShader.GLSL, Application.cpp:150-154).  The reference ships no fixtures
+for this half (parity unpinned, see oracle/gs4d_oracle.cpp header); these tests pin the algebra the shaders imply."""
+import numpy as np
+
+import scenes
+
+
+QROT = (0.9, 0.1, 0.3, 0.2)      # generic orientation: keeps tests away from the reference's axis-aligned vanishing case
+
+
+def one_splat(oracle, pos=(0, 0, 0), scale=(1, 1.5, 0.7), rgba=(0.9, 0.5, 0.1, 0.8), W=256, H=256, cam=((0, 0, 20.0), (0, 0, -1.0)), q=QROT):
+    cov = oracle.splat3d_cov(q, scale).reshape(3, 3)
+    rec = np.zeros((1, 24), np.float32)
+    rec[0, 0:3] = pos
+    rec[0, 4:8] = rgba
+    sig = np.zeros((4, 4), np.float32); sig[:3, :3] = cov; sig[3, 3] = 1.0
+    rec[0, 8:] = sig.reshape(-1)
+    view = oracle.look_at(cam[0], cam[1]); proj = oracle.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
+    return rec, view, proj
+
+
+def test_quad_is_half_sigma_and_gaussian_is_exp_minus_32_c2(oracle):
+    """Quad spans +-0.5 'S' while the Gaussian argument spans +-4 S (…Instanced.GLSL:145-146): alpha(u,v) = exp(-32(u^2+v^2))."""
+    W = H = 256
+    # slightly off-axis: an isotropic splat exactly on the optical axis is the reference's vanishing case (see the last test)
+    rec, view, proj = one_splat(oracle, pos=(0.6, 0.35, 0.0), scale=(10, 10, 10))
+    p = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H)
+    assert p["valid"][0] == 1
+    # near-isotropic: sigma' ~ scale/dist in tan units; quad half-extent ~ 0.5*sigma'*P11*H/2 pixels
+    expect_h = 0.5 * (10.0 / 20.0) * proj[5] * H / 2
+    half_side = [0.5 / np.hypot(p["a0x"][0], p["a0y"][0]), 0.5 / np.hypot(p["a1x"][0], p["a1y"][0])]
+    np.testing.assert_allclose(half_side, [expect_h, expect_h], rtol=0.05)
+    assert expect_h <= p["hx"][0] <= 1.5 * expect_h          # bounding box of the (rotated) quad
+    img = oracle.composite(p, None, oracle.MODE_4D, W, H, np.zeros((H, W, 4), np.float32))
+    cx, cy = float(p["cx"][0]), float(p["cy"][0])
+    hits = 0
+    for (i, j) in [(133, 131), (143, 129), (131, 151), (165, 165), (250, 128), (20, 20)]:
+        dx, dy = (i + 0.5) - cx, (j + 0.5) - cy
+        u = float(p["a0x"][0]) * dx + float(p["a0y"][0]) * dy
+        v = float(p["a1x"][0]) * dx + float(p["a1y"][0]) * dy
+        c = np.exp(-32.0 * (u * u + v * v))
+        a = 0.8 * c if (abs(u) <= 0.5 and abs(v) <= 0.5 and c >= 1e-4) else 0.0
+        hits += a > 0
+        np.testing.assert_allclose(img[j, i], [0.9 * a, 0.5 * a, 0.1 * a, a * a], rtol=3e-4, atol=1e-7)
+    assert hits >= 3
+    # rows of the affine map are orthogonal with equal norm 1/(2*half-extent): (u,v) are quad-local coordinates
+    n0 = np.hypot(p["a0x"][0], p["a0y"][0]); n1 = np.hypot(p["a1x"][0], p["a1y"][0])
+    assert abs(p["a0x"][0] * p["a1x"][0] + p["a0y"][0] * p["a1y"][0]) < 1e-6 * n0 * n1
+    # the quad's corners (|c| > 0.5365) are discarded: c < 1e-4 (Splat4DFragShader.GLSL:30)
+    corner = np.linalg.solve(np.array([[p["a0x"][0], p["a0y"][0]], [p["a1x"][0], p["a1y"][0]]], np.float64), [0.47, 0.47])
+    i, j = int(cx + corner[0]), int(cy + corner[1])
+    assert img[j, i, 3] == 0.0
+
+
+def test_blend_is_back_to_front_over_on_all_four_channels(oracle):
+    W = H = 64
+    recs = []
+    for z, col in ((0.0, (1, 0, 0, 0.5)), (5.0, (0, 1, 0, 0.25))):      # second one nearer to the camera at z=20
+        r, view, proj = one_splat(oracle, pos=(0.3, 0.2, z), scale=(30, 20, 25), rgba=col, W=W, H=H)
+        recs.append(r)
+    rec = np.concatenate(recs)
+    cam = (0, 0, 20.0)
+    img, perm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam, view, proj, W, H, clear=(0.2, 0.2, 0.2, 1.0), nthreads=1)
+    assert perm.tolist() == [0, 1]                     # far first
+    p = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H)
+    j = i = 32
+    d = np.array([0.2, 0.2, 0.2, 1.0])
+    for k in (0, 1):
+        u = ((i + 0.5) - p["cx"][k]) * p["a0x"][k] + ((j + 0.5) - p["cy"][k]) * p["a0y"][k]
+        v = ((i + 0.5) - p["cx"][k]) * p["a1x"][k] + ((j + 0.5) - p["cy"][k]) * p["a1y"][k]
+        a = rec[k, 7] * np.exp(-32 * (u * u + v * v))
+        src = np.array([rec[k, 4], rec[k, 5], rec[k, 6], a])
+        d = src * a + d * (1 - a)                      # Application.cpp:150: SRC_ALPHA / ONE_MINUS_SRC_ALPHA, alpha included
+    np.testing.assert_allclose(img[j, i], d, rtol=1e-5)
+    # drawing in the opposite order gives a different pixel: order matters
+    img2 = oracle.composite(p, np.array([1, 0], np.uint32), oracle.MODE_4D, W, H, oracle.clear_image(W, H, (0.2, 0.2, 0.2, 1.0)))
+    assert abs(img2[j, i, 0] - img[j, i, 0]) > 1e-2
+
+
+def test_time_conditioning_and_opacity(oracle):
+    """mu(t) = mu + (t - mu_t) * Sigma[0:3][3]/Sigma44 ; opacity_t = max(exp(-(t-mu_t)^2/(2 Sigma44)), uMinOpacity) (…GLSL:48-51, 83-95)."""
+    W = H = 128
+    q = QROT; vel = (3.0, 0.0, 0.0)
+    cov = oracle.splat4d_cov(q, (2, 3, 2.5), 1.0, 0.5, vel)
+    rec = np.zeros((1, 24), np.float32); rec[0, 0:4] = (0, 0, 0, 10.0); rec[0, 4:8] = (1, 1, 1, 1); rec[0, 8:] = cov
+    view = oracle.look_at((0, 0, 50.0), (0, 0, -1.0)); proj = oracle.perspective(scenes.FOV, W, H, 0.1, 5000.0)
+    s44 = cov[15]
+    cxs = []
+    for t in (8.0, 10.0, 12.0):
+        p = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, 0.0)
+        np.testing.assert_allclose(p["alpha"][0], np.exp(-0.5 * (t - 10.0) ** 2 / s44), rtol=1e-5)
+        cxs.append(p["cx"][0])
+    assert cxs[0] < cxs[1] < cxs[2]                    # moves along +x with velocity d
+    ppx = proj[0] * W / 2 / 50.0                       # pixels per world unit at that depth
+    np.testing.assert_allclose(cxs[2] - cxs[1], 2.0 * 3.0 * ppx, rtol=1e-3)
+    p = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, 40.0, 0.3)
+    assert p["alpha"][0] == np.float32(0.3)            # floor by uMinOpacity
+    # conditional covariance == the 3x3 the ctor was built from (Sigma3 + s d d^T - (s d)(s d)^T / s)
+    p0 = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, 10.0, 0.0)
+    rec3 = np.zeros((1, 24), np.float32); rec3[0, 4:8] = 1
+    s3 = np.zeros((4, 4), np.float32); s3[:3, :3] = oracle.splat3d_cov(q, (2, 3, 2.5)).reshape(3, 3); s3[3, 3] = 1; rec3[0, 8:] = s3.reshape(-1)
+    p3 = oracle.preprocess(oracle.MODE_4D, rec3, view, proj, W, H, 0.0, 0.0)
+    np.testing.assert_allclose([p0["hx"][0], p0["hy"][0]], [p3["hx"][0], p3["hy"][0]], rtol=1e-4)
+
+
+def test_cull_rules(oracle):
+    """cull iff ndc z<0 or z>1 or |x|,|y| > 1.2 (…Instanced.GLSL:108-115)."""
+    W, H = 200, 100
+    view = oracle.look_at((0, 0, 0.0), (0, 0, -1.0)); proj = oracle.perspective(scenes.FOV, W, H, 0.1, 5000.0)
+
+    def valid(pos):
+        rec, _, _ = one_splat(oracle, pos=pos, W=W, H=H)
+        return int(oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H)["valid"][0])
+    assert valid((0, 0, -10)) == 1
+    assert valid((0, 0, 10)) == 0                       # behind the camera: ndc z > 1
+    assert valid((0, 0, -0.15)) == 0                    # nearer than ~2fn/(f+n): ndc z < 0
+    t = np.tan(np.radians(30.0))
+    assert valid((0, 1.15 * t * 10, -10)) == 1 and valid((0, 1.25 * t * 10, -10)) == 0     # |y| bound 1.2
+    assert valid((1.15 * t * 2 * 10, 0, -10)) == 1 and valid((1.25 * t * 2 * 10, 0, -10)) == 0   # aspect 2
+
+
+def test_degenerate_axis_aligned_covariance_vanishes(oracle):
+    """upper[0][1] == 0 with upper[0][0] <= upper[1][1] -> normalize(vec2(0,0)) = NaN -> no fragments."""
+    W = H = 64
+    rec, view, proj = one_splat(oracle, scale=(1.0, 2.0, 1.0), W=W, H=H, q=(1, 0, 0, 0))     # on-axis, axis-aligned, sigma_x < sigma_y
+    p = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H)
+    assert p["valid"][0] == 0
+    rec, view, proj = one_splat(oracle, scale=(2.0, 1.0, 1.0), W=W, H=H, q=(1, 0, 0, 0))     # sigma_x > sigma_y: e0 = (0,-1), fine
+    assert oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H)["valid"][0] == 1
