@@ -70,6 +70,9 @@ def _load():
         "gs4d_host_splat4d_cov2q": (None, [vp, vp, vp, vp]),
         "gs4d_host_build_records_3d": (None, [sz, vp, vp, vp, vp, vp]),
         "gs4d_host_build_records_4d": (None, [sz, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "gs4d_host_scene_linear": (None, [sz, vp, i32, f32, f32, vp, f32, f32, f32, vp]),
+        "gs4d_host_scene_nonlinear": (None, [sz, vp, i32, f32, f32, f32, vp, f32, f32, f32, sz, vp]),
+        "gs4d_host_parse_vdata": (C.c_long, [C.c_char_p, vp, sz]),
         "gs4d_version": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
@@ -143,6 +146,32 @@ def build_records_4d(pos4, q_wxyz, scale3, lifetime, fade, dir3, rgba):
     rec = np.empty((n, 24), np.float32)
     _lib.gs4d_host_build_records_4d(n, _ptr(pos4), _ptr(q), _ptr(s), _ptr(life), _ptr(fd), _ptr(d), _ptr(col), _ptr(rec))
     return rec
+
+
+def scene_linear(verts6, steps=50, time_multiplier=1.0, object_scale=5.0, splat_scale=(4.0, 4.0, 1.0), lifetime=1.0, fade=0.5, speed=1.0):
+    """LinearMotion::init records (Scenes.h:258-279) with the class defaults (Scenes.h:186-201)."""
+    v = _f32(verts6).reshape(-1, 6)
+    rec = np.empty((v.shape[0] * steps, 24), np.float32)
+    _lib.gs4d_host_scene_linear(v.shape[0], _ptr(v), steps, time_multiplier, object_scale, _ptr(_f32(splat_scale)), lifetime, fade, speed, _ptr(rec))
+    return rec
+
+
+def scene_nonlinear(verts6, steps=92, angle_multiplier=4.0, radius=20.0, object_scale=5.0, splat_scale=(4.0, 4.0, 1.0), lifetime=1.0, fade=0.5, speed=20.0,
+                    max_records=None):
+    """NonLinearMotion::init records (Scenes.h:517-545) with the class defaults (Scenes.h:451-467)."""
+    v = _f32(verts6).reshape(-1, 6)
+    n = v.shape[0] * steps if max_records is None else min(max_records, v.shape[0] * steps)
+    rec = np.empty((n, 24), np.float32)
+    _lib.gs4d_host_scene_nonlinear(v.shape[0], _ptr(v), steps, angle_multiplier, radius, object_scale, _ptr(_f32(splat_scale)), lifetime, fade, speed, n, _ptr(rec))
+    return rec
+
+
+def parse_vdata(path, cap_vertices=1 << 20):
+    buf = np.empty((cap_vertices, 6), np.float32)
+    n = _lib.gs4d_host_parse_vdata(os.fsencode(path), _ptr(buf), cap_vertices)
+    if n < 0:
+        raise FileNotFoundError(path)
+    return buf[:min(n, cap_vertices)].copy()
 
 
 # ---- device context -----------------------------------------------------------------------------

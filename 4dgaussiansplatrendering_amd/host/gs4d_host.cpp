@@ -12,7 +12,13 @@
 // GLM 0.9.9.9 evaluation order is reproduced (float32, no contraction: build with -ffp-contract=off).
 #include "../../include/gs4d.h"
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
 
 namespace {
 
@@ -181,4 +187,110 @@ void gs4d_host_build_records_4d(size_t n, const float* pos4, const float* q_wxyz
     }
 }
 
+
+// ---- scene generators: the loops of LinearMotion::init (Scenes.h:258-279) and NonLinearMotion::init
+//      (Scenes.h:517-545) with GetModelExtrema (:75-91) and GetColor (:58-68; Utils.cpp lerp/mapf, note mapf ignores `a` in the
+//      numerator, Utils.cpp:130-133).  Pinned by the CRCs of the reference-generated SSBOs in tests/golden/manifest.json. ----
 } // extern "C"
+
+namespace {
+
+inline float fminu(float a, float b) { return a < b ? a : b; }          // Utils::minf
+inline float fmaxu(float a, float b) { return a > b ? a : b; }          // Utils::maxf
+inline float lerpu(float a, float b, float t) { return a + ((b - a) * t); }
+inline float mapfu(float x, float a, float b, float c, float d) { return c + ((x / (b - a)) * (d - c)); }
+inline float clamp01(float x) { const float lo = (x < 0.0f) ? 0.0f : x; return (1.0f < lo) ? 1.0f : lo; }     // glm::clamp = min(max(x,0),1)
+
+struct Extrema { float mn[3], mx[3]; };
+Extrema extrema(const float* v6, size_t n) {
+    Extrema e; for (int k = 0; k < 3; ++k) { e.mx[k] = -INFINITY; e.mn[k] = INFINITY; }
+    for (size_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { const float p = v6[6 * i + k]; e.mx[k] = fmaxu(p, e.mx[k]); e.mn[k] = fminu(p, e.mn[k]); }
+    return e;
+}
+void get_color(const float pos[3], const Extrema& e, const float nrm[3], float out[4], float mina = 0.65f, float maxa = 1.0f, float lower = 0.0f) {
+    const float t0 = 0.0f * nrm[0], t1 = -1.0f * nrm[1], t2 = 0.0f * nrm[2];
+    const float d = (t0 + t1) + t2;                                       // glm::dot({0,-1,0}, normal)
+    const float max_bright = mapfu(-d, -1.0f, 1.0f, mina, maxa);
+    for (int k = 0; k < 3; ++k) out[k] = clamp01(lerpu(lower, max_bright, ((pos[k] - e.mn[k]) / (e.mx[k] - e.mn[k]))));
+    out[3] = clamp01(1.0f);
+}
+// vec3(glm::rotate(vec4(1,0,0,0), angle, vec3(0,1,0)))  (gtx/rotate_vector.inl:66-74 -> ext/matrix_transform.inl:18-46)
+void rotate_forward_about_y(float angle, float out[3]) {
+    const float c = std::cos(angle), s = std::sin(angle);
+    const float inv = 1.0f / std::sqrt((0.0f * 0.0f + 1.0f * 1.0f) + 0.0f * 0.0f);
+    const float ax[3] = { 0.0f * inv, 1.0f * inv, 0.0f * inv };
+    const float tmp[3] = { (1.0f - c) * ax[0], (1.0f - c) * ax[1], (1.0f - c) * ax[2] };
+    float Rm[3][3];
+    Rm[0][0] = c + tmp[0] * ax[0];          Rm[0][1] = tmp[0] * ax[1] + s * ax[2]; Rm[0][2] = tmp[0] * ax[2] - s * ax[1];
+    Rm[1][0] = tmp[1] * ax[0] - s * ax[2];  Rm[1][1] = c + tmp[1] * ax[1];         Rm[1][2] = tmp[1] * ax[2] + s * ax[0];
+    Rm[2][0] = tmp[2] * ax[0] + s * ax[1];  Rm[2][1] = tmp[2] * ax[1] - s * ax[0]; Rm[2][2] = c + tmp[2] * ax[2];
+    // Result[c] = I[0]*R[c][0] + I[1]*R[c][1] + I[2]*R[c][2]; Result[3] = I[3]
+    float M[4][4];
+    for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 4; ++r) {
+        const float i0 = r == 0 ? 1.0f : 0.0f, i1 = r == 1 ? 1.0f : 0.0f, i2 = r == 2 ? 1.0f : 0.0f;
+        M[cc][r] = (i0 * Rm[cc][0] + i1 * Rm[cc][1]) + i2 * Rm[cc][2];
+    }
+    for (int r = 0; r < 4; ++r) M[3][r] = r == 3 ? 1.0f : 0.0f;
+    const float v[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
+    for (int r = 0; r < 3; ++r) out[r] = (M[0][r] * v[0] + M[1][r] * v[1]) + (M[2][r] * v[2] + M[3][r] * v[3]);     // mat4*vec4: (Mul0+Mul1)+(Mul2+Mul3)
+}
+
+} // namespace
+
+extern "C" {
+
+void gs4d_host_scene_linear(size_t nverts, const float* verts6, int steps, float time_multiplier, float object_scale, const float splat_scale[3],
+                            float lifetime, float fade, float speed, float* records24) {
+    const Extrema e = extrema(verts6, nverts);
+    const float up[3] = { 0.0f, 1.0f, 0.0f };
+    size_t o = 0;
+    for (int dt = 0; dt < steps; ++dt) for (size_t i = 0; i < nverts; ++i, ++o) {
+        const float* pos = verts6 + 6 * i; const float* nrm = pos + 3;
+        const float off = float(dt * time_multiplier);                      // dir * float(dt * m_lin_time_multiplyer), dir = (1,0,0)
+        float* rec = records24 + 24 * o;
+        rec[0] = (object_scale * pos[0]) + 1.0f * off; rec[1] = (object_scale * pos[1]) + 0.0f * off; rec[2] = (object_scale * pos[2]) + 0.0f * off; rec[3] = float(dt);
+        get_color(pos, e, nrm, rec + 4);
+        float q[4]; gs4d_host_quat_look_at(nrm, up, q);
+        const float ninv = 1.0f / std::sqrt((1.0f * 1.0f + 0.0f * 0.0f) + 0.0f * 0.0f);   // glm::normalize(dir)
+        const float dir[3] = { (1.0f * ninv) * speed, (0.0f * ninv) * speed, (0.0f * ninv) * speed };
+        gs4d_host_splat4d_cov(q, splat_scale, lifetime, fade, dir, rec + 8);
+    }
+}
+
+void gs4d_host_scene_nonlinear(size_t nverts, const float* verts6, int steps, float angle_multiplier, float radius, float object_scale,
+                               const float splat_scale[3], float lifetime, float fade, float speed, size_t max_records, float* records24) {
+    const Extrema e = extrema(verts6, nverts);
+    const float up[3] = { 0.0f, 1.0f, 0.0f };
+    const float RAD = 0.01745329251994329576923690768489f;
+    size_t o = 0;
+    for (int dt = 0; dt < steps && o < max_records; ++dt) {
+        float cur[3], nxt[3];
+        rotate_forward_about_y(float(dt * angle_multiplier) * RAD, cur);
+        rotate_forward_about_y(float((dt + 1) * angle_multiplier) * RAD, nxt);
+        for (size_t i = 0; i < nverts && o < max_records; ++i, ++o) {
+            const float* pos = verts6 + 6 * i; const float* nrm = pos + 3;
+            float* rec = records24 + 24 * o;
+            for (int k = 0; k < 3; ++k) rec[k] = (object_scale * pos[k]) + (cur[k] * radius);
+            rec[3] = float(dt);
+            get_color(pos, e, nrm, rec + 4);
+            float q[4]; gs4d_host_quat_look_at(nrm, up, q);
+            const float dir[3] = { (nxt[0] - cur[0]) * speed, (nxt[1] - cur[1]) * speed, (nxt[2] - cur[2]) * speed };
+            gs4d_host_splat4d_cov(q, splat_scale, lifetime, fade, dir, rec + 8);
+        }
+    }
+}
+
+// VData::parse (VDataParser.h:25-58): whitespace-separated std::stof tokens, 6 per vertex (position, normal).
+// Returns the number of vertices in the file (which may exceed cap_vertices; only cap_vertices are written), or -1 if it cannot be opened.
+long gs4d_host_parse_vdata(const char* path, float* verts6, size_t cap_vertices) {
+    std::ifstream file(path);
+    if (!file.is_open()) return -1;
+    std::vector<float> vals; std::string word;
+    while (file >> word) vals.push_back(std::stof(word));
+    const size_t n = vals.size() / 6;
+    for (size_t i = 0; i < n && i < cap_vertices; ++i) std::memcpy(verts6 + 6 * i, vals.data() + 6 * i, 24);
+    return (long)n;
+}
+
+} // extern "C"
+

@@ -12,8 +12,12 @@ STRICT   := -ffp-contract=off
 
 OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(HOST)/gs4d_host.o
 
-.PHONY: all lib oracle ref clean
-all: lib oracle
+.PHONY: all lib oracle ref clean demo
+all: lib oracle demo
+DEMO := $(HOST)/scene_replay
+demo: $(DEMO)
+$(DEMO): $(HOST)/scene_replay.cpp $(HOST)/gs4d_compat.h include/gs4d.h $(LIB)
+	g++ -O2 -std=c++17 -Wall -o $@ $(HOST)/scene_replay.cpp -L$(PKG) -lgs4d -Wl,-rpath,'$$ORIGIN/..'
 lib: $(LIB)
 
 $(CSRC)/sort.o: $(CSRC)/sort.hip $(CSRC)/gs4d_internal.h include/gs4d.h
@@ -34,5 +38,5 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) $(DEMO)
 	$(MAKE) -C oracle clean

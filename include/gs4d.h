@@ -133,6 +133,13 @@ GS4D_API void gs4d_host_build_records_3d(size_t n, const float* pos3, const floa
 GS4D_API void gs4d_host_build_records_4d(size_t n, const float* pos4, const float* q_wxyz, const float* scale3, const float* lifetime, const float* fade,
                                 const float* dir3, const float* rgba, float* records24);
 
+/* Scene generators and the .vdata loader (f2): the CPU loops that fill the SSBO before the path starts. */
+GS4D_API void gs4d_host_scene_linear(size_t nverts, const float* verts6, int steps, float time_multiplier, float object_scale, const float splat_scale[3],
+                                     float lifetime, float fade, float speed, float* records24);                      /* Scenes.h:258-279, defaults :186-201 */
+GS4D_API void gs4d_host_scene_nonlinear(size_t nverts, const float* verts6, int steps, float angle_multiplier, float radius, float object_scale,
+                                        const float splat_scale[3], float lifetime, float fade, float speed, size_t max_records, float* records24); /* Scenes.h:517-545, defaults :451-467 */
+GS4D_API long gs4d_host_parse_vdata(const char* path, float* verts6, size_t cap_vertices);                            /* VDataParser.h:25-58 */
+
 GS4D_API const char* gs4d_version(void);
 
 #ifdef __cplusplus
