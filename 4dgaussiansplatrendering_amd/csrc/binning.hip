@@ -141,22 +141,22 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict_
     if (j == m - 1) ranges[2 * cur + 1] = m;
 }
 
-hipError_t bin_scratch_reserve(BinScratch& b, size_t ninst, size_t ntiles) {
+hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size_t ntiles) {
     hipError_t e;
     size_t nb = (ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS);
     if (nb < 1) nb = 1;
     if (b.block_cap < nb) {
-        if (b.block_sums) (void)hipFree(b.block_sums);
+        if (b.block_sums) { (void)hipStreamSynchronize(st); (void)hipFree(b.block_sums); }
         b.block_sums = nullptr; b.block_cap = 0;
         if ((e = hipMalloc(&b.block_sums, nb * 4)) != hipSuccess) return e;
         b.block_cap = nb;
     }
     if (!b.total) {
         if ((e = hipMalloc(&b.total, 16)) != hipSuccess) return e;
-        if ((e = hipMemset(b.total, 0, 16)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(b.total, 0, 16, st)) != hipSuccess) return e;
     }
     if (b.tiles_cap < ntiles) {
-        if (b.ranges) (void)hipFree(b.ranges);
+        if (b.ranges) { (void)hipStreamSynchronize(st); (void)hipFree(b.ranges); }
         b.ranges = nullptr; b.tiles_cap = 0;
         if ((e = hipMalloc(&b.ranges, ntiles * 8)) != hipSuccess) return e;
         b.tiles_cap = ntiles;

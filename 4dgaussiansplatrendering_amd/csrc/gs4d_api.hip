@@ -60,7 +60,8 @@ struct gs4d_ctx {
     uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;
     SortScratch depth_sort, pair_sort;
     BinScratch bin;
-    uint32_t* host_total = nullptr;    // pinned, 4 words
+    uint32_t* host_total = nullptr;    // pinned, 4 words of the binning total + 1 word of dev_err
+    uint32_t* dev_err = nullptr;       // device word: raised by a kernel whose bounded spin timed out
     hipEvent_t pending_ev = nullptr;
     bool pending = false;
     DrawArgs pending_args;
@@ -122,7 +123,7 @@ int ensure_pairs(gs4d_ctx* c, size_t cap) {
 // Enqueue binning -> tile sort -> ranges -> composite for projected records already in c->proj.
 int enqueue_raster(gs4d_ctx* c, const uint32_t* order, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
-    HIPCHK(c, bin_scratch_reserve(c->bin, ninst, ntiles));
+    HIPCHK(c, bin_scratch_reserve(c->st, c->bin, ninst, ntiles));
     {
         StageTimer t(c, GS4D_T_BINNING);
         HIPCHK(c, launch_binning(c->st, c->bin, c->proj, order, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap));
@@ -138,6 +139,7 @@ int enqueue_raster(gs4d_ctx* c, const uint32_t* order, size_t ninst, size_t nrec
         HIPCHK(c, launch_composite(c->st, c->proj, c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
     }
     HIPCHK(c, hipMemcpyAsync(c->host_total, c->bin.total, 16, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipMemcpyAsync(c->host_total + 4, c->dev_err, 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipEventRecord(c->pending_ev, c->st));
     return GS4D_OK;
 }
@@ -189,6 +191,7 @@ int resolve_pending(gs4d_ctx* c) {
     while (c->pending) {
         HIPCHK(c, hipEventSynchronize(c->pending_ev));
         c->pending = false;
+        if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "radix sort: a look-back spin timed out on the device (results of this frame are invalid)");
         const uint64_t total = (uint64_t)c->host_total[2] | ((uint64_t)c->host_total[3] << 32);
         if (!c->host_total[1]) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)");
@@ -245,8 +248,11 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
     c->st = c->own_st;
     if ((e = hipEventCreateWithFlags(&c->pending_ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
-    if ((e = hipHostMalloc((void**)&c->host_total, 16, hipHostMallocDefault)) != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
-    memset(c->host_total, 0, 16);
+    if ((e = hipHostMalloc((void**)&c->host_total, 32, hipHostMallocDefault)) != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
+    memset(c->host_total, 0, 32);
+    if ((e = hipMalloc(&c->dev_err, 64)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
+    if ((e = hipMemsetAsync(c->dev_err, 0, 64, c->st)) != hipSuccess) return bail(hipfail(c, e, "hipMemset"));
+    c->depth_sort.err = c->dev_err; c->pair_sort.err = c->dev_err;
     int rc = alloc_fb(c, width, height);
     if (rc) return bail(rc);
     *out = c;
@@ -264,6 +270,7 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (c->pair_vals) (void)hipFree(c->pair_vals);
     sort_scratch_free(c->depth_sort); sort_scratch_free(c->pair_sort); bin_scratch_free(c->bin);
     if (c->host_total) (void)hipHostFree(c->host_total);
+    if (c->dev_err) (void)hipFree(c->dev_err);
     if (c->pending_ev) (void)hipEventDestroy(c->pending_ev);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
@@ -461,7 +468,9 @@ int gs4d_finish(gs4d_ctx* c) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->host_total + 4, c->dev_err, 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
+    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "radix sort: a look-back spin timed out on the device");
     return GS4D_OK;
 }
 

@@ -26,11 +26,13 @@ struct Uniforms {
 
 // ---- sort.hip ----
 struct SortScratch {
-    uint32_t* keys2 = nullptr; uint32_t* vals2 = nullptr; size_t cap = 0;   // ping-pong buffers (radix_sort.hpp:192-216 scratch)
-    uint32_t* hist = nullptr; size_t hist_cap = 0;                          // [256][nblocks]
-    uint32_t* totals = nullptr;                                             // [256]
+    uint32_t* keys2 = nullptr; uint32_t* vals2 = nullptr; size_t cap = 0;   // scratch B and C (keys2[2*cap], vals2[2*cap]; one allocation) — radix_sort.hpp:192-216 scratch
+    uint32_t* hist = nullptr; size_t hist_cap = 0;                          // two [4][256] digit histograms (alternating), then the look-back words
+    int flip = 0;
+    uint32_t* totals = nullptr;                                             // [256] spare words (err word when `err` is not set)
+    uint32_t* err = nullptr;                                                // not owned: device word raised when a look-back spin times out
 };
-hipError_t sort_scratch_reserve(SortScratch& s, size_t n);
+hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n);
 void sort_scratch_free(SortScratch& s);
 // Stable LSD radix sort of (key,val) pairs on bits [0, key_bits).  n_dev == nullptr: n is exact.  Otherwise the element
 // count is read on the device from *n_dev (<= n, n is the launch capacity); the result always lands back in keys/vals.
@@ -49,7 +51,7 @@ struct BinScratch {
     uint32_t* total = nullptr;        // [0] = number of tile-list entries, [1] = overflow flag
     uint32_t* ranges = nullptr; size_t tiles_cap = 0;   // [2*ntiles] start,end
 };
-hipError_t bin_scratch_reserve(BinScratch& b, size_t ninst, size_t ntiles);
+hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size_t ntiles);
 void bin_scratch_free(BinScratch& b);
 // order == nullptr: instance k draws record k
 hipError_t launch_binning(hipStream_t st, BinScratch& b, const float4* proj, const uint32_t* order, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,7 +118,7 @@ def main():
     for k in range(args.warmup):
         step(k)
     fence()
-    ctx.set_profiling(True)                     # HIP events on the launch stream, averaged over the timed frames
+    ctx.set_profiling(not args.no_stage_events)    # HIP events on the launch stream, averaged over the timed frames
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)

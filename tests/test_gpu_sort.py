@@ -28,7 +28,7 @@ def _sort_on_gpu(ctx, keys, vals):
     return k, v
 
 
-@pytest.mark.parametrize("n", [2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 100003, 1 << 20, (3 << 20) + 17])
+@pytest.mark.parametrize("n", [2, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 100003, 1 << 20, (3 << 20) + 17, (5 << 20) + 3])
 def test_sort_random_full_range(ctx, oracle, n):
     rng = np.random.default_rng(n)
     keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
