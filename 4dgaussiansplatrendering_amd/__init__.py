@@ -288,7 +288,14 @@ class Context:
 
     # measurement
     def set_profiling(self, on):
-        self._chk(_lib.gs4d_set_profiling(self._h, 1 if on else 0))
+        """False: off; True: every stage; an iterable of stage names: only those (each timed stage costs two event records per frame)."""
+        if isinstance(on, (list, tuple, set)):
+            mask = 0
+            for name in on:
+                mask |= 1 << STAGES.index(name)
+        else:
+            mask = 0x3F if on else 0
+        self._chk(_lib.gs4d_set_profiling(self._h, mask))
 
     def timings(self):
         ms = np.zeros(len(STAGES), np.float32)

@@ -8,6 +8,8 @@
 //
 // Counts stay on the device: the total number of entries is written to total[0] (and an overflow flag to total[1] when it
 // exceeds the preallocated capacity); later kernels read it there, so a frame needs no host synchronisation.
+// Counting, scanning and emitting are ONE launch (chained scan over workgroup totals); the per-record pixel rectangles are read
+// from a compact 8-byte array (L2/Infinity-Cache resident) instead of the 64-byte projected records.
 #include "gs4d_internal.h"
 
 namespace gs4d {
@@ -24,7 +26,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-// exclusive scan over the 256 threads of a block; returns the exclusive prefix, *total = block sum
+// exclusive scan over the 256 threads of a block; returns the exclusive prefix, total = block sum
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /* __shared__[4] */, uint32_t& total) {
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     uint32_t inc = wave_incl_scan(v);
@@ -40,51 +42,6 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /
 
 struct Rect { uint32_t tx0, ty0, tx1, ty1, count; };
 
-__device__ __forceinline__ Rect load_rect(const float4* __restrict__ proj, const uint32_t* __restrict__ order, uint32_t k, uint32_t ninst, uint32_t nrecords, uint32_t& rec) {
-    Rect r = { 0, 0, 0, 0, 0 };
-    rec = 0;
-    if (k >= ninst) return r;
-    rec = order ? order[k] : k;
-    if (rec >= nrecords) return r;           // index past the bound SSBO: GL would read undefined data; we draw nothing
-    float4 c = proj[(size_t)rec * 4 + 2];
-    uint32_t r0 = __float_as_uint(c.z), r1 = __float_as_uint(c.w);
-    uint32_t x0 = r0 & 0xFFFFu, y0 = r0 >> 16, x1 = r1 & 0xFFFFu, y1 = r1 >> 16;
-    if (x0 > x1 || y0 > y1) return r;
-    r.tx0 = x0 / TILE; r.ty0 = y0 / TILE; r.tx1 = x1 / TILE; r.ty1 = y1 / TILE;
-    r.count = (r.tx1 - r.tx0 + 1u) * (r.ty1 - r.ty0 + 1u);
-    return r;
-}
-
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_count(const float4* __restrict__ proj, const uint32_t* __restrict__ order, uint32_t ninst, uint32_t nrecords,
-                                                           uint32_t* __restrict__ block_sums) {
-    __shared__ uint32_t wsum[4];
-    uint32_t s = 0, rec;
-    const uint32_t base = blockIdx.x * (BIN_THREADS * BIN_ITEMS);
-#pragma unroll
-    for (int j = 0; j < BIN_ITEMS; ++j) s += load_rect(proj, order, base + j * BIN_THREADS + threadIdx.x, ninst, nrecords, rec).count;
-    uint32_t total;
-    (void)block_excl_scan(s, wsum, total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-// single workgroup: exclusive scan of block_sums in place; total[0] = sum (saturated), total[1] = (sum > cap), total[2..3] = 64-bit sum
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_scan(uint32_t* __restrict__ block_sums, uint32_t nblocks, uint32_t cap, uint32_t* __restrict__ total) {
-    __shared__ uint32_t wsum[4];
-    unsigned long long run = 0;             // 64-bit: a close-up scene can exceed 2^32 entries; that must read as overflow, not wrap
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += BIN_THREADS) {
-        uint32_t b = b0 + threadIdx.x;
-        uint32_t v = b < nblocks ? block_sums[b] : 0u, tot;
-        uint32_t ex = block_excl_scan(v, wsum, tot);
-        if (b < nblocks) block_sums[b] = (uint32_t)run + ex;     // only meaningful while run <= cap < 2^32
-        run += tot;
-    }
-    if (threadIdx.x == 0) {
-        total[0] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;
-        total[1] = run > (unsigned long long)cap ? 1u : 0u;
-        total[2] = (uint32_t)run; total[3] = (uint32_t)(run >> 32);
-    }
-}
-
 __device__ __forceinline__ void emit_tiles(const Rect& r, uint32_t off, uint32_t rec, uint32_t tiles_x, uint32_t first, uint32_t stride,
                                            uint32_t* __restrict__ pk, uint32_t* __restrict__ pv) {
     const uint32_t wx = r.tx1 - r.tx0 + 1u;
@@ -95,32 +52,97 @@ __device__ __forceinline__ void emit_tiles(const Rect& r, uint32_t off, uint32_t
     }
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const float4* __restrict__ proj, const uint32_t* __restrict__ order, uint32_t ninst, uint32_t nrecords,
-                                                          const uint32_t* __restrict__ block_sums, const uint32_t* __restrict__ total, uint32_t tiles_x,
-                                                          uint32_t* __restrict__ pk, uint32_t* __restrict__ pv) {
+// status[b] is one 64-bit {flag:2,value:62} granule per workgroup, written/polled with agent-scope relaxed atomics (same
+// hand-off form as the radix sort's look-back words); it is zeroed by the preprocess kernel of the same draw.
+constexpr unsigned long long BS_AGG = 1ull << 62, BS_INCL = 2ull << 62, BS_VAL = (1ull << 62) - 1ull;
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t ninst, uint32_t nrecords,
+                                                          unsigned long long* status, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
+                                                          uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err) {
     __shared__ uint32_t wsum[4];
-    if (total[1]) return;                     // capacity overflow: the host re-runs the draw with larger lists
-    uint32_t run = block_sums[blockIdx.x];
-    const uint32_t base = blockIdx.x * (BIN_THREADS * BIN_ITEMS);
-    const uint32_t lane = threadIdx.x & 63u;
+    __shared__ unsigned long long s_prefix;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, blk = blockIdx.x;
+    const uint32_t base = blk * (BIN_THREADS * BIN_ITEMS);
+    Rect r[BIN_ITEMS]; uint32_t rec[BIN_ITEMS], off[BIN_ITEMS];
+    uint32_t run = 0;
 #pragma unroll
     for (int j = 0; j < BIN_ITEMS; ++j) {
-        uint32_t rec;
-        Rect r = load_rect(proj, order, base + j * BIN_THREADS + threadIdx.x, ninst, nrecords, rec);
-        uint32_t tot;
-        uint32_t off = run + block_excl_scan(r.count, wsum, tot);
-        run += tot;
-        const bool big = r.count > 32u;
-        if (!big) emit_tiles(r, off, rec, tiles_x, 0u, 1u, pk, pv);
+        const uint32_t k = base + j * BIN_THREADS + tid;
+        r[j] = Rect{ 0, 0, 0, 0, 0 }; rec[j] = 0;
+        if (k < ninst) {
+            rec[j] = order ? order[k] : k;
+            if (rec[j] < nrecords) {              // an index past the bound SSBO: GL would read undefined data; we draw nothing
+                const uint2 rr = rects[rec[j]];
+                const uint32_t x0 = rr.x & 0xFFFFu, y0 = rr.x >> 16, x1 = rr.y & 0xFFFFu, y1 = rr.y >> 16;
+                if (x0 <= x1 && y0 <= y1) {
+                    r[j].tx0 = x0 / TILE; r[j].ty0 = y0 / TILE; r[j].tx1 = x1 / TILE; r[j].ty1 = y1 / TILE;
+                    r[j].count = (r[j].tx1 - r[j].tx0 + 1u) * (r[j].ty1 - r[j].ty0 + 1u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < BIN_ITEMS; ++j) { uint32_t tot; off[j] = run + block_excl_scan(r[j].count, wsum, tot); run += tot; }
+    // publish this workgroup's total, look back for the exclusive prefix (wave 0, 64 predecessors per step)
+    if (tid < 64) {
+        unsigned long long prefix = 0;
+        if (blk == 0) { if (lane == 0) __hip_atomic_store(status, BS_INCL | (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        else {
+            if (lane == 0) __hip_atomic_store(status + blk, BS_AGG | (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t p = (int64_t)blk - 1;
+            uint32_t spins = 0;
+            while (true) {
+                const int64_t idx = p - (int64_t)lane;
+                const unsigned long long v = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : BS_INCL;   // before workgroup 0: inclusive 0
+                const uint32_t f = (uint32_t)(v >> 62);
+                const uint64_t none = __ballot(f == 0u), incl = __ballot(f == 2u);
+                const uint64_t low = incl & (0ull - incl);                                     // nearest INCL
+                const uint64_t upto = incl ? (low | (low - 1ull)) : ~0ull;                       // lanes up to and including it
+                if (none & upto) {                          // a needed word is not published yet
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 21)) { if (lane == 0) atomicExch(err, 1u); break; }
+                    continue;
+                }
+                prefix += wave_sum_u64(((upto >> lane) & 1ull) ? (v & BS_VAL) : 0ull);
+                if (incl) break;
+                p -= 64;
+            }
+            if (lane == 0) __hip_atomic_store(status + blk, BS_INCL | ((prefix + run) & BS_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_prefix = prefix;
+            if (blk == gridDim.x - 1) {                     // the last workgroup knows the grand total
+                const unsigned long long g = prefix + run;
+                total[0] = g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g;
+                total[1] = g > (unsigned long long)cap ? 1u : 0u;
+                total[2] = (uint32_t)g; total[3] = (uint32_t)(g >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long pre = s_prefix;
+#pragma unroll
+    for (int j = 0; j < BIN_ITEMS; ++j) {
+        const unsigned long long o64 = pre + off[j];
+        const bool fits = o64 + r[j].count <= (unsigned long long)cap;      // entries beyond the capacity are not written; the draw is re-run
+        const uint32_t o = (uint32_t)o64;
+        const bool big = fits && r[j].count > 32u;
+        if (fits && !big) emit_tiles(r[j], o, rec[j], tiles_x, 0u, 1u, pk, pv);
         // large footprints: the whole wave writes one splat's entries
         uint64_t m = __ballot(big);
         while (m) {
-            int src = __ffsll((long long)m) - 1;
+            const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
             Rect rr;
-            rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.tx1 = __shfl(r.tx1, src, 64); rr.ty1 = __shfl(r.ty1, src, 64);
-            rr.count = __shfl(r.count, src, 64);
-            uint32_t o2 = __shfl(off, src, 64), rec2 = __shfl(rec, src, 64);
+            rr.tx0 = __shfl(r[j].tx0, src, 64); rr.ty0 = __shfl(r[j].ty0, src, 64); rr.tx1 = __shfl(r[j].tx1, src, 64); rr.ty1 = __shfl(r[j].ty1, src, 64);
+            rr.count = __shfl(r[j].count, src, 64);
+            const uint32_t o2 = __shfl(o, src, 64), rec2 = __shfl(rec[j], src, 64);
             emit_tiles(rr, o2, rec2, tiles_x, lane, 64u, pk, pv);
         }
     }
@@ -145,45 +167,37 @@ hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size
     hipError_t e;
     size_t nb = (ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS);
     if (nb < 1) nb = 1;
-    if (b.block_cap < nb) {
-        if (b.block_sums) { (void)hipStreamSynchronize(st); (void)hipFree(b.block_sums); }
-        b.block_sums = nullptr; b.block_cap = 0;
-        if ((e = hipMalloc(&b.block_sums, nb * 4)) != hipSuccess) return e;
-        b.block_cap = nb;
-    }
     if (!b.total) {
         if ((e = hipMalloc(&b.total, 16)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(b.total, 0, 16, st)) != hipSuccess) return e;
     }
-    if (b.tiles_cap < ntiles) {
+    if (b.block_cap < nb || b.tiles_cap < ntiles) {
         if (b.ranges) { (void)hipStreamSynchronize(st); (void)hipFree(b.ranges); }
-        b.ranges = nullptr; b.tiles_cap = 0;
-        if ((e = hipMalloc(&b.ranges, ntiles * 8)) != hipSuccess) return e;
-        b.tiles_cap = ntiles;
+        const size_t nb2 = nb > b.block_cap ? nb : b.block_cap, nt2 = ntiles > b.tiles_cap ? ntiles : b.tiles_cap;
+        b.ranges = nullptr; b.status = nullptr; b.block_cap = b.tiles_cap = 0;
+        // one allocation, zeroed as a whole each draw: [ranges: 2*tiles u32][status: blocks u64]
+        if ((e = hipMalloc(&b.ranges, nt2 * 8 + nb2 * 8)) != hipSuccess) return e;
+        b.status = reinterpret_cast<unsigned long long*>(b.ranges + 2 * nt2);
+        b.block_cap = nb2; b.tiles_cap = nt2;
     }
     return hipSuccess;
 }
 
 void bin_scratch_free(BinScratch& b) {
-    if (b.block_sums) (void)hipFree(b.block_sums);
     if (b.total) (void)hipFree(b.total);
     if (b.ranges) (void)hipFree(b.ranges);
     b = BinScratch();
 }
 
-hipError_t launch_binning(hipStream_t st, BinScratch& b, const float4* proj, const uint32_t* order, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
-                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap) {
+hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
+                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err) {
     (void)tiles_y;
     const uint32_t nb = (uint32_t)((ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    k_bin_count<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(proj, order, (uint32_t)ninst, (uint32_t)nrecords, b.block_sums);
-    k_bin_scan<<<dim3(1), dim3(BIN_THREADS), 0, st>>>(b.block_sums, nb, (uint32_t)pair_cap, b.total);
-    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(proj, order, (uint32_t)ninst, (uint32_t)nrecords, b.block_sums, b.total, (uint32_t)tiles_x, pair_keys, pair_vals);
+    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err);
     return hipGetLastError();
 }
 
 hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pair_keys, size_t pair_cap, size_t ntiles) {
-    hipError_t e = hipMemsetAsync(b.ranges, 0, ntiles * 8, st);
-    if (e != hipSuccess) return e;
     k_tile_ranges<<<dim3((unsigned)((pair_cap + 255) / 256)), dim3(256), 0, st>>>(pair_keys, b.total, (uint32_t)ntiles, b.ranges);
     return hipGetLastError();
 }

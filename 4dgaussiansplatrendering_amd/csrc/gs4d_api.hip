@@ -57,6 +57,7 @@ struct gs4d_ctx {
     bool fb_is_clear = true;           // framebuffer content == clear colour, not yet materialised
     // per-draw scratch
     float4* proj = nullptr; size_t proj_cap = 0; size_t proj_n = 0;
+    uint2* rects = nullptr;            // compact pixel rectangles, one per projected record
     uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;
     SortScratch depth_sort, pair_sort;
     BinScratch bin;
@@ -69,7 +70,7 @@ struct gs4d_ctx {
     // profiling
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
     static constexpr int PROF_FRAMES = 128;
-    bool profiling = false;
+    unsigned profiling = 0;                    // bit s set: stage s is timed
     int prof_frame = 0;
     std::vector<hipEvent_t> ev0, ev1;          // [PROF_FRAMES][GS4D_T_COUNT], created on first use
     std::vector<uint8_t> ran;
@@ -90,7 +91,7 @@ Buffer* getbuf(gs4d_ctx* c, gs4d_buf b) { return (b != 0 && b < c->bufs.size() &
 struct StageTimer {
     gs4d_ctx* c; int slot;
     StageTimer(gs4d_ctx* c_, int id) : c(c_), slot(-1) {
-        if (c->profiling && c->prof_frame < gs4d_ctx::PROF_FRAMES) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], c->st); }
+        if (((c->profiling >> id) & 1u) && c->prof_frame < gs4d_ctx::PROF_FRAMES) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], c->st); }
     }
     ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(c->ev1[slot], c->st); c->ran[slot] = 1; } }
 };
@@ -121,12 +122,12 @@ int ensure_pairs(gs4d_ctx* c, size_t cap) {
 }
 
 // Enqueue binning -> tile sort -> ranges -> composite for projected records already in c->proj.
-int enqueue_raster(gs4d_ctx* c, const uint32_t* order, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear) {
+int enqueue_raster(gs4d_ctx* c, const uint32_t* order, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, bool zeroed) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
-    HIPCHK(c, bin_scratch_reserve(c->st, c->bin, ninst, ntiles));
     {
         StageTimer t(c, GS4D_T_BINNING);
-        HIPCHK(c, launch_binning(c->st, c->bin, c->proj, order, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap));
+        if (!zeroed) HIPCHK(c, hipMemsetAsync(c->bin.ranges, 0, c->bin.zero_words() * 4, c->st));      // re-run of a draw: preprocess did not run
+        HIPCHK(c, launch_binning(c->st, c->bin, c->rects, order, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err));
     }
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     {
@@ -163,25 +164,29 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances == 0 || nrec == 0) return GS4D_OK;
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
+    HIPCHK(c, bin_scratch_reserve(c->st, c->bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
     if (preprocess) {
         if (c->proj_cap < npre) {
             HIPCHK(c, hipStreamSynchronize(c->st));
             if (c->proj) (void)hipFree(c->proj);
-            c->proj = nullptr; c->proj_cap = 0;
+            if (c->rects) (void)hipFree(c->rects);
+            c->proj = nullptr; c->rects = nullptr; c->proj_cap = 0;
             HIPCHK(c, hipMalloc(&c->proj, npre * 64));
+            HIPCHK(c, hipMalloc(&c->rects, npre * 8));
             c->proj_cap = npre;
         }
         if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
         StageTimer t(c, GS4D_T_PREPROCESS);
-        if (a.quads) HIPCHK(c, launch_preprocess_3d(c->st, (const float*)data->d, npre, a.u, c->W, c->H, c->proj));
-        else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->st, (const float*)data->d, npre, a.u, c->W, c->H, c->proj));
-        else HIPCHK(c, launch_preprocess_4d(c->st, data->soa, npre, a.u, c->W, c->H, c->proj));
+        const PreOut po = { c->proj, c->rects, c->bin.ranges, (uint32_t)c->bin.zero_words() };
+        if (a.quads) HIPCHK(c, launch_preprocess_3d(c->st, (const float*)data->d, npre, a.u, c->W, c->H, po));
+        else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->st, (const float*)data->d, npre, a.u, c->W, c->H, po));
+        else HIPCHK(c, launch_preprocess_4d(c->st, data->soa, npre, a.u, c->W, c->H, po));
         c->proj_n = npre;
     }
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
     if (c->pair_cap < want) { int rc = ensure_pairs(c, want); if (rc) return rc; }
-    return enqueue_raster(c, order, a.instances, npre, premult, a.fb_was_clear);
+    return enqueue_raster(c, order, a.instances, npre, premult, a.fb_was_clear, preprocess);
 }
 
 // A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
@@ -266,6 +271,7 @@ void gs4d_destroy(gs4d_ctx* c) {
     for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); }
     if (c->fb) (void)hipFree(c->fb);
     if (c->proj) (void)hipFree(c->proj);
+    if (c->rects) (void)hipFree(c->rects);
     if (c->pair_keys) (void)hipFree(c->pair_keys);
     if (c->pair_vals) (void)hipFree(c->pair_vals);
     sort_scratch_free(c->depth_sort); sort_scratch_free(c->pair_sort); bin_scratch_free(c->bin);
@@ -515,15 +521,15 @@ int gs4d_set_stream(gs4d_ctx* c, void* hip_stream) {
 }
 
 // ---- measurement / test hooks ----
-int gs4d_set_profiling(gs4d_ctx* c, int on) {
+int gs4d_set_profiling(gs4d_ctx* c, int stage_mask) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
-    if (on && c->ev0.empty()) {
+    if (stage_mask && c->ev0.empty()) {
         const size_t n = (size_t)gs4d_ctx::PROF_FRAMES * GS4D_T_COUNT;
         c->ev0.assign(n, nullptr); c->ev1.assign(n, nullptr); c->ran.assign(n, 0);
         for (size_t i = 0; i < n; ++i) { HIPCHK(c, hipEventCreate(&c->ev0[i])); HIPCHK(c, hipEventCreate(&c->ev1[i])); }
     }
-    c->profiling = on != 0;
+    c->profiling = (unsigned)stage_mask & 0x3Fu;
     c->prof_frame = 0;
     std::fill(c->ran.begin(), c->ran.end(), 0);
     return GS4D_OK;

@@ -41,21 +41,26 @@ hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, 
 
 // ---- preprocess.hip ----
 hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* 6 planes of n float4 */);
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& u, int W, int H, float4* proj);
-hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, float4* proj);
-hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, float4* proj);
+// Each preprocess launch also writes the compact pixel rectangle of every record and zeroes `zero_words` words at `zero` (the
+// binning control block of the same draw), so the draw needs no memset launch.
+struct PreOut { float4* proj; uint2* rects; uint32_t* zero; uint32_t zero_words; };
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& u, int W, int H, PreOut out);
+hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, PreOut out);
+hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, PreOut out);
 
 // ---- binning.hip ----
 struct BinScratch {
-    uint32_t* block_sums = nullptr; size_t block_cap = 0;
-    uint32_t* total = nullptr;        // [0] = number of tile-list entries, [1] = overflow flag
-    uint32_t* ranges = nullptr; size_t tiles_cap = 0;   // [2*ntiles] start,end
+    uint32_t* total = nullptr;        // [0] = number of tile-list entries (saturated), [1] = overflow flag, [2..3] = 64-bit count
+    uint32_t* ranges = nullptr; size_t tiles_cap = 0;           // [2*tiles] start,end — followed in the same allocation by
+    unsigned long long* status = nullptr; size_t block_cap = 0; // the chained-scan words of the binning workgroups
+    // ranges+status are zeroed together at the start of every draw (by the preprocess kernel, or a memset when a draw is re-run)
+    size_t zero_words() const { return 2 * tiles_cap + 2 * block_cap; }
 };
 hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size_t ntiles);
 void bin_scratch_free(BinScratch& b);
 // order == nullptr: instance k draws record k
-hipError_t launch_binning(hipStream_t st, BinScratch& b, const float4* proj, const uint32_t* order, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
-                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap);
+hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
+                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err);
 hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pair_keys, size_t pair_cap, size_t ntiles);
 
 // ---- composite.hip ----

@@ -66,7 +66,7 @@ __device__ __forceinline__ void eigen2(float u00, float u01, float u10, float u1
 __device__ __forceinline__ bool fin(float x) { return isfinite(x); }
 
 // Window-space set-up + record store.  ncx,ncy = NDC centre; kx,ky = NDC scale of the quad offset.
-__device__ __forceinline__ void emit(float4* __restrict__ proj, uint32_t i, bool valid, const Quad& q, float ncx, float ncy, float kx, float ky,
+__device__ __forceinline__ void emit(const PreOut& out, uint32_t i, bool valid, const Quad& q, float ncx, float ncy, float kx, float ky,
                                      int W, int H, float r, float g, float b, float alpha) {
     float cx = 0, cy = 0, a0x = 0, a0y = 0, a1x = 0, a1y = 0, hx = 0, hy = 0;
     uint32_t rect0 = 1u, rect1 = 0u;           // empty
@@ -96,7 +96,8 @@ __device__ __forceinline__ void emit(float4* __restrict__ proj, uint32_t i, bool
         }
     }
     if (!valid) { cx = cy = a0x = a0y = a1x = a1y = hx = hy = 0.0f; alpha = 0.0f; rect0 = 1u; rect1 = 0u; }
-    float4* o = proj + (size_t)i * 4;
+    out.rects[i] = make_uint2(rect0, rect1);
+    float4* o = out.proj + (size_t)i * 4;
     o[0] = make_float4(cx, cy, a0x, a0y);
     o[1] = make_float4(a1x, a1y, alpha, r);
     o[2] = make_float4(g, b, __uint_as_float(rect0), __uint_as_float(rect1));
@@ -151,8 +152,9 @@ __device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict__ soa, uint32_t n, PU u, float4* __restrict__ proj) {
+__global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict__ soa, uint32_t n, PU u, PreOut out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t z = i; z < out.zero_words; z += gridDim.x * 256u) out.zero[z] = 0u;
     if (i >= n) return;
     const float4 pos = soa[i], col = soa[(size_t)n + i];
     const float4 s0 = soa[(size_t)2 * n + i], s1 = soa[(size_t)3 * n + i], s2 = soa[(size_t)4 * n + i], s3 = soa[(size_t)5 * n + i];
@@ -173,11 +175,12 @@ __global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict_
         for (int r = 0; r < 3; ++r) C[c][r] = S[c][r] - a[r] * tv[c];              // :89-95
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, mx, my, mz, C, q, ncx, ncy);
-    emit(proj, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w);
+    emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w);
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__ verts, uint32_t n, PU u, float4* __restrict__ proj) {
+__global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__ verts, uint32_t n, PU u, PreOut out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t z = i; z < out.zero_words; z += gridDim.x * 256u) out.zero[z] = 0u;
     if (i >= n) return;
     const float* v = verts + (size_t)72 * i;      // vertex 0 of the quad: {vpos2, spos3, col4, sig9}
     float C[3][3];
@@ -187,11 +190,12 @@ __global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__
         for (int r = 0; r < 3; ++r) C[c][r] = v[9 + 3 * c + r];
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, v[2], v[3], v[4], C, q, ncx, ncy);
-    emit(proj, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8]);
+    emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8]);
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__ recs, uint32_t n, PU u, float4* __restrict__ proj) {
+__global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__ recs, uint32_t n, PU u, PreOut out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t z = i; z < out.zero_words; z += gridDim.x * 256u) out.zero[z] = 0u;
     if (i >= n) return;
     const float* rec = recs + (size_t)12 * i;
     const float* P = u.P;
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__
     float clipz = P[10] * zc + P[14] * wc4;
     bool valid = (clipw > 0.0f) && !(clipz < -clipw || clipz > clipw);
     float kx = P[0] / clipw, ky = P[5] / clipw;
-    emit(proj, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
+    emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
 }
 
 static PU make_pu(const Uniforms& un, int W, int H) {
@@ -221,19 +225,19 @@ static PU make_pu(const Uniforms& un, int W, int H) {
     return u;
 }
 
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, float4* proj) {
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, PreOut out) {
     if (n == 0) return hipSuccess;
-    k_preprocess_4d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(soa, (uint32_t)n, make_pu(un, W, H), proj);
+    k_preprocess_4d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(soa, (uint32_t)n, make_pu(un, W, H), out);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, float4* proj) {
+hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, PreOut out) {
     if (n == 0) return hipSuccess;
-    k_preprocess_3d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(verts72, (uint32_t)n, make_pu(un, W, H), proj);
+    k_preprocess_3d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(verts72, (uint32_t)n, make_pu(un, W, H), out);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, float4* proj) {
+hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, PreOut out) {
     if (n == 0) return hipSuccess;
-    k_preprocess_2d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(rec48, (uint32_t)n, make_pu(un, W, H), proj);
+    k_preprocess_2d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(rec48, (uint32_t)n, make_pu(un, W, H), out);
     return hipGetLastError();
 }
 

@@ -15,6 +15,8 @@
 #include "gs4d_internal.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 namespace gs4d {
 
@@ -205,7 +207,7 @@ __device__ __forceinline__ bool os_lookback(const uint32_t* st, int32_t hi, int3
 template <int ITEMS>
 __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
                                                         const uint32_t* __restrict__ ghist /* [4][256] */,
-                                                        uint32_t* status /* [tiles][256] of this pass, zeroed */, uint32_t* gstatus /* [groups][256], zeroed */, uint32_t* err, int dbg) {
+                                                        uint32_t* status /* [tiles][256] of this pass, zeroed */, uint32_t* gstatus /* [groups][256], zeroed */, uint32_t* err, int dbg, unsigned long long* stamps) {
     constexpr uint32_t TILE_KEYS = RS_THREADS * ITEMS;
     __shared__ uint32_t skeys[TILE_KEYS];
     __shared__ uint32_t svals[TILE_KEYS];
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
     const uint32_t tile = blockIdx.x;
     const uint32_t ntiles = (n + TILE_KEYS - 1u) / TILE_KEYS;
     if (tile >= ntiles) return;                                   // uniform
+    if (stamps && tid == 0) stamps[tile * 8 + 0] = wall_clock64();
     const int shift = 8 * pass;
     if (tid < OS_MAX_PASSES) s_live[tid] = 1u;
 #pragma unroll
@@ -244,6 +247,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
         val[j] = valid ? vals_in[i] : 0u;
     }
     const uint32_t digit_base = block_excl_scan_256(tot, s_tmp, tid);          // overlaps the loads above
+    if (stamps && tid == 0) { stamps[tile * 8 + 1] = wall_clock64(); stamps[tile * 8 + 6] = key[0]; }
 
     const uint64_t lt = (1ull << lane) - 1ull;
     volatile uint32_t* wc = wcnt[w];
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
     uint32_t cnt = 0;
 #pragma unroll
     for (int k = 0; k < RS_WAVES; ++k) { const uint32_t t = wcnt[k][tid]; wcnt[k][tid] = cnt; cnt += t; }
+    if (stamps && tid == 0) stamps[tile * 8 + 2] = wall_clock64();
     // Publish, then look back — two levels, so that the walk costs ~3 memory round trips however many tiles start together:
     // tiles in groups of OS_GROUP; the last tile of a group also publishes the group's aggregate / inclusive prefix.
     uint32_t* my = status + (size_t)tile * 256u + tid;
@@ -290,6 +295,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
         __hip_atomic_store(my, OS_FLAG_INCL | ((prefix + cnt) & OS_VAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (last_in_group) __hip_atomic_store(gstatus + (size_t)grp * 256u + tid, OS_FLAG_INCL | ((prefix + cnt) & OS_VAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (stamps && tid == 0) stamps[tile * 8 + 3] = wall_clock64();
     // exclusive scan of the tile's digit counts -> local run starts
     loff[tid] = block_excl_scan_256(cnt, s_tmp, tid);
     gpos[tid] = digit_base + prefix;
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
         }
     }
     __syncthreads();
+    if (stamps && tid == 0) stamps[tile * 8 + 4] = wall_clock64();
     const uint32_t tcount = min(TILE_KEYS, n - tbase);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
             vals_out[o] = svals[l];
         }
     }
+    if (stamps && tid == 0) stamps[tile * 8 + 5] = wall_clock64();
 }
 
 // Exactly one live pass leaves the result in scratch buffer 1: copy it back (device-side decision; otherwise a no-op launch).
@@ -367,6 +375,9 @@ void sort_scratch_free(SortScratch& s) {
 template <int ITEMS>
 static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes) {
     static const int dbgk = getenv("GS4D_SORT_DBG") ? atoi(getenv("GS4D_SORT_DBG")) : 0;
+    static const char* stampf = getenv("GS4D_SORT_STAMP_FILE");
+    unsigned long long* stamps = nullptr;
+    if (stampf) { if (hipMalloc(&stamps, (size_t)((n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS)) * 64) != hipSuccess) stamps = nullptr; }
     const uint32_t tile_keys = RS_THREADS * ITEMS;
     const uint32_t tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
     uint32_t* ghist = s.hist + (s.flip ? 1024 : 0);
@@ -383,8 +394,16 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     const uint32_t hist_blocks = (uint32_t)std::min<size_t>((n / 16 + 255) / 256 + 1, 256);      // few workgroups: each flushes 256 global atomics per pass
     k_os_hist<<<dim3(hist_blocks), dim3(256), 0, st>>>(keys, (uint32_t)n, n_dev, passes, ghist, ghist_next, status, status_words);
     for (int p = 0; p < passes; ++p)
-        k_os_pass<ITEMS><<<dim3(tiles), dim3(RS_THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, status + p * per_pass, status + p * per_pass + (size_t)tiles * 256, s.err ? s.err : s.totals, dbgk);
+        k_os_pass<ITEMS><<<dim3(tiles), dim3(RS_THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, status + p * per_pass, status + p * per_pass + (size_t)tiles * 256, s.err ? s.err : s.totals, dbgk, (stampf && p == 0) ? stamps : nullptr);
     k_os_copyback<<<dim3(512), dim3(256), 0, st>>>(b, (uint32_t)n, n_dev, passes, ghist);
+    if (stampf) {   // debugging aid: dump per-tile wall-clock stamps (100 MHz) of pass 0
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)tiles * 8);
+        (void)hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        FILE* f = fopen(stampf, "w");
+        if (f) { for (uint32_t t = 0; t < tiles; ++t) { for (int k = 0; k < 6; ++k) fprintf(f, "%llu ", h[t * 8 + k] - h[0]); fprintf(f, "\n"); } fclose(f); }
+        (void)hipFree(stamps);
+    }
     return hipGetLastError();
 }
 

@@ -112,7 +112,7 @@ GS4D_API int gs4d_set_stream(gs4d_ctx* ctx, void* hip_stream);
 GS4D_API int gs4d_finish(gs4d_ctx* ctx);                                          /* hipStreamSynchronize                   */
 
 /* ---- measurement / test hooks ---- */
-GS4D_API int gs4d_set_profiling(gs4d_ctx* ctx, int on);
+GS4D_API int gs4d_set_profiling(gs4d_ctx* ctx, int stage_mask);                   /* bit (1 << GS4D_T_x) times stage x; 0 = off, 0x3F = every stage; each timed stage costs two event records per frame */
 GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);             /* blocking; -1.0f for stages that did not run */
 GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[4]);                    /* [0] tile-list entries of the last draw, [1] capacity, [2] re-runs after overflow, [3] tiles */
 /* Projected records of the last draw, 16 floats per record in record order:
