@@ -42,13 +42,16 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /
 
 struct Rect { uint32_t tx0, ty0, tx1, ty1, count; };
 
+// writes the entries of one splat and counts their tile-id digits for the radix sort that follows (no separate histogram launch)
 __device__ __forceinline__ void emit_tiles(const Rect& r, uint32_t off, uint32_t rec, uint32_t tiles_x, uint32_t first, uint32_t stride,
-                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv) {
+                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t (*h)[256], int passes) {
     const uint32_t wx = r.tx1 - r.tx0 + 1u;
     for (uint32_t j = first; j < r.count; j += stride) {
-        uint32_t ty = r.ty0 + j / wx, tx = r.tx0 + j % wx;
-        pk[off + j] = ty * tiles_x + tx;
+        const uint32_t ty = r.ty0 + j / wx, tx = r.tx0 + j % wx;
+        const uint32_t id = ty * tiles_x + tx;
+        pk[off + j] = id;
         pv[off + j] = rec;
+        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(id >> (8 * p)) & 255u], 1u);
     }
 }
 
@@ -64,9 +67,12 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t ninst, uint32_t nrecords,
                                                           unsigned long long* status, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
-                                                          uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err) {
+                                                          uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
+                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host) {
     __shared__ uint32_t wsum[4];
     __shared__ unsigned long long s_prefix;
+    __shared__ uint32_t h[OS_MAX_PASSES][256];
+    os_hist_clear(h, threadIdx.x);
     const uint32_t tid = threadIdx.x, lane = tid & 63u, blk = blockIdx.x;
     const uint32_t base = blk * (BIN_THREADS * BIN_ITEMS);
     Rect r[BIN_ITEMS]; uint32_t rec[BIN_ITEMS], off[BIN_ITEMS];
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
                 const uint64_t upto = incl ? (low | (low - 1ull)) : ~0ull;                       // lanes up to and including it
                 if (none & upto) {                          // a needed word is not published yet
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 21)) { if (lane == 0) atomicExch(err, 1u); break; }
+                    if (++spins > (1u << 21)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
                     continue;
                 }
                 prefix += wave_sum_u64(((upto >> lane) & 1ull) ? (v & BS_VAL) : 0ull);
@@ -122,6 +128,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
                 total[0] = g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g;
                 total[1] = g > (unsigned long long)cap ? 1u : 0u;
                 total[2] = (uint32_t)g; total[3] = (uint32_t)(g >> 32);
+                // copy for the host (pinned, mapped): read after the draw's event, no copy launch
+                total_host[0] = total[0]; total_host[1] = total[1]; total_host[2] = total[2]; total_host[3] = total[3];
             }
         }
     }
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
         const bool fits = o64 + r[j].count <= (unsigned long long)cap;      // entries beyond the capacity are not written; the draw is re-run
         const uint32_t o = (uint32_t)o64;
         const bool big = fits && r[j].count > 32u;
-        if (fits && !big) emit_tiles(r[j], o, rec[j], tiles_x, 0u, 1u, pk, pv);
+        if (fits && !big) emit_tiles(r[j], o, rec[j], tiles_x, 0u, 1u, pk, pv, h, passes);
         // large footprints: the whole wave writes one splat's entries
         uint64_t m = __ballot(big);
         while (m) {
@@ -143,9 +151,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
             rr.tx0 = __shfl(r[j].tx0, src, 64); rr.ty0 = __shfl(r[j].ty0, src, 64); rr.tx1 = __shfl(r[j].tx1, src, 64); rr.ty1 = __shfl(r[j].ty1, src, 64);
             rr.count = __shfl(r[j].count, src, 64);
             const uint32_t o2 = __shfl(o, src, 64), rec2 = __shfl(rec[j], src, 64);
-            emit_tiles(rr, o2, rec2, tiles_x, lane, 64u, pk, pv);
+            emit_tiles(rr, o2, rec2, tiles_x, lane, 64u, pk, pv, h, passes);
         }
     }
+    __syncthreads();
+    os_hist_flush(h, ghist, passes, tid);
 }
 
 __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict__ pk, const uint32_t* __restrict__ total, uint32_t ntiles, uint32_t* __restrict__ ranges) {
@@ -190,10 +200,10 @@ void bin_scratch_free(BinScratch& b) {
 }
 
 hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
-                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err) {
+                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host) {
     (void)tiles_y;
     const uint32_t nb = (uint32_t)((ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err);
+    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host);
     return hipGetLastError();
 }
 

@@ -61,8 +61,10 @@ struct gs4d_ctx {
     uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;
     SortScratch depth_sort, pair_sort;
     BinScratch bin;
-    uint32_t* host_total = nullptr;    // pinned, 4 words of the binning total + 1 word of dev_err
-    uint32_t* dev_err = nullptr;       // device word: raised by a kernel whose bounded spin timed out
+    uint32_t* host_total = nullptr;    // pinned + mapped: [0..3] the binning total of the last draw, [4] the error word kernels raise when a bounded spin times out
+    uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
+    uint32_t* dev_err = nullptr;       // = host_total_dev + 4
+    gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
     hipEvent_t pending_ev = nullptr;
     bool pending = false;
     DrawArgs pending_args;
@@ -124,24 +126,27 @@ int ensure_pairs(gs4d_ctx* c, size_t cap) {
 // Enqueue binning -> tile sort -> ranges -> composite for projected records already in c->proj.
 int enqueue_raster(gs4d_ctx* c, const uint32_t* order, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, bool zeroed) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
+    const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
     {
         StageTimer t(c, GS4D_T_BINNING);
         if (!zeroed) HIPCHK(c, hipMemsetAsync(c->bin.ranges, 0, c->bin.zero_words() * 4, c->st));      // re-run of a draw: preprocess did not run
-        HIPCHK(c, launch_binning(c->st, c->bin, c->rects, order, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err));
+        hipError_t he = hipSuccess;
+        uint32_t* ph = sort_hist_slot(c->st, c->pair_sort, c->pair_cap, &he);      // the emit kernel also counts the tile-id digits
+        if (!ph) return hipfail(c, he, "sort_hist_slot");
+        HIPCHK(c, launch_binning(c->st, c->bin, c->rects, order, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err,
+                                 ph, tile_passes, c->host_total_dev));
     }
-    int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     {
         StageTimer t(c, GS4D_T_PAIRSORT);
-        HIPCHK(c, radix_sort_pairs(c->st, c->pair_sort, c->pair_keys, c->pair_vals, c->pair_cap, c->bin.total, tile_bits));
+        HIPCHK(c, radix_sort_pairs(c->st, c->pair_sort, c->pair_keys, c->pair_vals, c->pair_cap, c->bin.total, tile_bits, true));
         HIPCHK(c, launch_tile_ranges(c->st, c->bin, c->pair_keys, c->pair_cap, ntiles));
     }
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
         HIPCHK(c, launch_composite(c->st, c->proj, c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
     }
-    HIPCHK(c, hipMemcpyAsync(c->host_total, c->bin.total, 16, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipMemcpyAsync(c->host_total + 4, c->dev_err, 4, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipEventRecord(c->pending_ev, c->st));
+    HIPCHK(c, hipEventRecord(c->pending_ev, c->st));       // the last binning workgroup wrote the total straight into pinned host memory
     return GS4D_OK;
 }
 
@@ -253,10 +258,10 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
     c->st = c->own_st;
     if ((e = hipEventCreateWithFlags(&c->pending_ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
-    if ((e = hipHostMalloc((void**)&c->host_total, 32, hipHostMallocDefault)) != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
-    memset(c->host_total, 0, 32);
-    if ((e = hipMalloc(&c->dev_err, 64)) != hipSuccess) return bail(hipfail(c, e, "hipMalloc"));
-    if ((e = hipMemsetAsync(c->dev_err, 0, 64, c->st)) != hipSuccess) return bail(hipfail(c, e, "hipMemset"));
+    if ((e = hipHostMalloc((void**)&c->host_total, 64, hipHostMallocMapped)) != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
+    memset(c->host_total, 0, 64);
+    if ((e = hipHostGetDevicePointer((void**)&c->host_total_dev, c->host_total, 0)) != hipSuccess) return bail(hipfail(c, e, "hipHostGetDevicePointer"));
+    c->dev_err = c->host_total_dev + 4;
     c->depth_sort.err = c->dev_err; c->pair_sort.err = c->dev_err;
     int rc = alloc_fb(c, width, height);
     if (rc) return bail(rc);
@@ -276,7 +281,6 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (c->pair_vals) (void)hipFree(c->pair_vals);
     sort_scratch_free(c->depth_sort); sort_scratch_free(c->pair_sort); bin_scratch_free(c->bin);
     if (c->host_total) (void)hipHostFree(c->host_total);
-    if (c->dev_err) (void)hipFree(c->dev_err);
     if (c->pending_ev) (void)hipEventDestroy(c->pending_ev);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
@@ -415,8 +419,10 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     if (K == V) return fail(c, GS4D_E_INVALID, "sort_pairs: keys and values must be different buffers");
     if (n >= 0xFFFFFFFFull || K->bytes < n * 4 || V->bytes < n * 4) return fail(c, GS4D_E_INVALID, "sort_pairs: buffers smaller than n elements");
     if (touches_pending(c, keys) || touches_pending(c, vals)) { int rc = resolve_pending(c); if (rc) return rc; }
+    // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
+    const bool have_hist = c->depth_sort.hist_pending && keys == c->kg_buf && K->version == c->kg_ver && n == c->kg_n;
     StageTimer t(c, GS4D_T_SORT);
-    HIPCHK(c, radix_sort_pairs(c->st, c->depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, 32));
+    HIPCHK(c, radix_sort_pairs(c->st, c->depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, 32, have_hist));
     K->version++; V->version++;
     return GS4D_OK;
 }
@@ -431,9 +437,13 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     if (n == 0) return GS4D_OK;
     if (touches_pending(c, keys) || touches_pending(c, idx)) { int rc = resolve_pending(c); if (rc) return rc; }
     int rc = ensure_soa(c, *D); if (rc) return rc;
+    hipError_t he = hipSuccess;
+    uint32_t* kh = sort_hist_slot(c->st, c->depth_sort, n, &he);
+    if (!kh) return hipfail(c, he, "sort_hist_slot");
     StageTimer tm(c, GS4D_T_KEYGEN);
-    HIPCHK(c, launch_keygen(c->st, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d));
+    HIPCHK(c, launch_keygen(c->st, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d, kh));
     K->version++; I->version++;
+    c->kg_buf = keys; c->kg_ver = K->version; c->kg_n = n;
     return GS4D_OK;
 }
 
@@ -474,7 +484,6 @@ int gs4d_finish(gs4d_ctx* c) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(c->host_total + 4, c->dev_err, 4, hipMemcpyDeviceToHost, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
     if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "radix sort: a look-back spin timed out on the device");
     return GS4D_OK;

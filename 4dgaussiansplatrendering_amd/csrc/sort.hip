@@ -25,65 +25,76 @@ namespace gs4d {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, const float4* __restrict__ sig3, uint32_t n, float t,
                                                 float camx, float camy, float camz, float4 vrow2 /* view row 2: V[2],V[6],V[10],V[14] */, int key_mode,
-                                                float* __restrict__ keys, uint32_t* __restrict__ idx) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    float4 p = pos[i];
-    float4 s = sig3[i];
-    float key;
-    if (key_mode == GS4D_KEY_REF_INV_EUCLID) {
-        float ct = t - p.w;                        // Scenes.h:30
-        float x = p.x + s.x * ct;                  // :31-33  (sig[3].xyz, NOT divided by Sigma44)
-        float y = p.y + s.y * ct;
-        float z = p.z + s.z * ct;
-        float dx = x - camx, dy = y - camy, dz = z - camz;          // :317
-        key = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);            // :318
-    } else {
-        // extra mode: view-space depth of the shader's conditioned mean (Splat4DVertexShaderInstanced.GLSL:86)
-        float k = (1.0f / s.w) * (t - p.w);
-        float x = p.x + k * s.x, y = p.y + k * s.y, z = p.z + k * s.z;
-        float zv = ((vrow2.x * x + vrow2.y * y) + vrow2.z * z) + vrow2.w;
-        key = 1.0f / fmaxf(-zv, 1e-20f);
+                                                float* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ ghist /* digit histograms of the keys, for the sort */) {
+    __shared__ uint32_t h[OS_MAX_PASSES][256];
+    os_hist_clear(h, threadIdx.x);
+    __syncthreads();
+    for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {      // uniform trip count per workgroup
+        const uint32_t i = i0 + threadIdx.x;
+        const bool in = i < n;
+        float key = 0.0f;
+        if (in) {
+            const float4 p = pos[i];
+            const float4 s = sig3[i];
+            if (key_mode == GS4D_KEY_REF_INV_EUCLID) {
+                float ct = t - p.w;                        // Scenes.h:30
+                float x = p.x + s.x * ct;                  // :31-33  (sig[3].xyz, NOT divided by Sigma44)
+                float y = p.y + s.y * ct;
+                float z = p.z + s.z * ct;
+                float dx = x - camx, dy = y - camy, dz = z - camz;          // :317
+                key = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);            // :318
+            } else {
+                // extra mode: view-space depth of the shader's conditioned mean (Splat4DVertexShaderInstanced.GLSL:86)
+                float k = (1.0f / s.w) * (t - p.w);
+                float x = p.x + k * s.x, y = p.y + k * s.y, z = p.z + k * s.z;
+                float zv = ((vrow2.x * x + vrow2.y * y) + vrow2.z * z) + vrow2.w;
+                key = 1.0f / fmaxf(-zv, 1e-20f);
+            }
+            keys[i] = key;
+            idx[i] = i;
+        }
+        os_hist_add(h, __float_as_uint(key), in, OS_MAX_PASSES);
     }
-    keys[i] = key;
-    idx[i] = i;
+    __syncthreads();
+    os_hist_flush(h, ghist, OS_MAX_PASSES, threadIdx.x);
 }
 
-hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx) {
+hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist) {
     if (n == 0) return hipSuccess;
     float4 vr = make_float4(view[2], view[6], view[10], view[14]);
-    k_keygen<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);     // grid-stride: bounds the histogram flush to 1024 workgroups
+    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------
-// radix sort
-// ------------------------------------------------------------------------------------------------
-constexpr int RS_THREADS = 256;
-constexpr int RS_WAVES = RS_THREADS / 64;
-
-// ------------------------------------------------------------------------------------------------
-// Single-pass-per-digit radix sort with a chained scan (decoupled look-back)
+// radix sort: one launch per 8-bit digit, chained scan with a two-level decoupled look-back
 //
-//   k_os_hist : one launch builds the global digit histograms of ALL passes (keys read once, LDS-privatised) and zeroes the
-//               look-back words of this sort and the histogram of the NEXT sort (so no memset launch is needed).
-//   k_os_pass : one launch per 8-bit digit.  A workgroup ranks the keys of its tile (wave64 ballot match), publishes its
-//               per-digit counts as {flag,value} words, looks back over its predecessors' words to obtain its exclusive prefix,
-//               reorders the tile in LDS and writes each digit's run to its final place with consecutive lanes on consecutive
-//               addresses.  Traffic per pass: keys+values read once, written once.
-//   A pass whose digit is the same for every key (e.g. sign+exponent byte of the positive depth keys) is a stable identity and
-//   is skipped ON THE DEVICE: every workgroup derives, from the histograms, which passes are live and which of three buffers
-//   (caller's, scratch B, scratch C) it reads and writes, so that the last live pass lands in the caller's buffers.
-// Inter-workgroup hand-off: each status word is ONE naturally aligned 32-bit {flag:2,value:30} granule written by one
-// agent-scope relaxed atomic store and polled with agent-scope relaxed atomic loads (bypass L1, write-through) — the
-// data-tagged granule form of cdna_hip_programming.md Guideline 16 (R2): no separate flag, hence no ordering requirement.
+//   histogram  : global digit histograms of ALL passes, [4][256].  Produced by k_os_hist (keys read once, LDS-privatised) — or,
+//                for free, by the kernel that wrote the keys (k_keygen for depth keys, k_bin_emit for tile ids), in which case no
+//                histogram launch happens at all.
+//   k_os_pass  : a workgroup ranks the keys of its tile (wave64 ballot match), publishes its per-digit counts, looks back over its
+//                predecessors to obtain its exclusive prefix, reorders the tile in LDS and writes each digit's run to its final
+//                place with consecutive lanes on consecutive addresses.  Traffic per pass: keys+values read once, written once.
+//   A pass whose digit is the same for every key (e.g. the sign+exponent byte of positive depth keys) is a stable identity and is
+//   skipped ON THE DEVICE: every workgroup derives from the histograms which passes are live and which of three buffers (caller's,
+//   scratch B, scratch C) it reads and writes, so that the last live pass lands in the caller's buffers without a copy.
+// Inter-workgroup hand-off: each look-back word is ONE naturally aligned 64-bit granule {epoch:30, flag:2, value:32}, written by one
+// agent-scope relaxed atomic store and polled with agent-scope relaxed atomic loads (bypass L1, write-through) — the data-tagged
+// granule form of cdna_hip_programming.md Guideline 16 (R2): no separate flag, hence no ordering requirement.  The epoch (one per
+// launch) makes words of earlier launches read as "not published", so the words are never zeroed.
+// Look-back is two-level (tiles in groups of OS_GROUP; the last tile of a group publishes the group's total): when all tiles of a
+// small sort start together, a tile needs ~3 memory round trips instead of one per ~32 predecessors.
 // Tile id = blockIdx.x: a tile waits only for lower-numbered tiles, which the dispatcher has started earlier (observed in-order
-// dispatch; not an API guarantee), so every spin is bounded: on time-out the kernel raises `err` and leaves, and the host
-// reports the frame as failed instead of hanging the GPU or returning wrong data.
+// dispatch; not an API guarantee), so every spin is bounded: on time-out the kernel raises `err` and leaves, and the host reports
+// the frame as failed instead of hanging the GPU or returning wrong data.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t OS_FLAG_AGG = 1u << 30, OS_FLAG_INCL = 2u << 30, OS_VAL_MASK = (1u << 30) - 1u;
-constexpr int OS_MAX_PASSES = 4;
 constexpr uint32_t OS_GROUP = 32;         // tiles per look-back group
+typedef unsigned long long u64;
+constexpr u64 OS_AGG = 1ull, OS_INCL = 2ull;
+
+__device__ __forceinline__ u64 os_word(uint32_t epoch, u64 flag, uint32_t value) { return ((u64)epoch << 34) | (flag << 32) | (u64)value; }
+__device__ __forceinline__ uint32_t os_flag(u64 w, uint32_t epoch) { return (uint32_t)(w >> 34) == epoch ? (uint32_t)(w >> 32) & 3u : 0u; }
 
 struct OsBufs { uint32_t* k[3]; uint32_t* v[3]; };      // [0] caller's buffers, [1],[2] scratch
 
@@ -92,30 +103,12 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane
     for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off, 64); if (lane >= (unsigned)off) v += t; }
     return v;
 }
-// exclusive scan over 256 threads (4 waves); `tmp` = __shared__ uint32_t[4]; two barriers
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* tmp, uint32_t tid) {
-    const uint32_t lane = tid & 63u, w = tid >> 6;
-    const uint32_t inc = wave_incl_scan_u32(v, lane);
-    __syncthreads();
-    if (lane == 63u) tmp[w] = inc;
-    __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) if ((unsigned)k < w) base += tmp[k];
-    return base + inc - v;
-}
-
 __global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int passes,
-                                                 uint32_t* __restrict__ ghist /* [4][256], zero on entry */, uint32_t* __restrict__ ghist_next /* zeroed here */,
-                                                 uint32_t* __restrict__ status, uint32_t status_words) {
+                                                 uint32_t* __restrict__ ghist /* [OS_REPL][4][256], zero on entry */) {
     __shared__ uint32_t h[OS_MAX_PASSES][256];
     const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-#pragma unroll
-    for (int p = 0; p < OS_MAX_PASSES; ++p) h[p][tid] = 0;
-    // housekeeping for the passes of this sort and the histogram of the next one
-    for (uint32_t i = blockIdx.x * 256u + tid; i < status_words; i += gridDim.x * 256u) status[i] = 0u;
-    if (blockIdx.x == 0) { for (int p = 0; p < OS_MAX_PASSES; ++p) ghist_next[p * 256 + tid] = 0u; }
+    const uint32_t tid = threadIdx.x;
+    os_hist_clear(h, tid);
     __syncthreads();
     const uint32_t nvec = n / 4u;
     const uint4* k4 = reinterpret_cast<const uint4*>(keys);
@@ -127,91 +120,120 @@ __global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ ke
         for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * stride; in[u] = i < nvec; kk[u] = in[u] ? k4[i] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t kv[4] = { kk[u].x, kk[u].y, kk[u].z, kk[u].w };
-            const uint64_t act = __ballot(in[u]);
-            if (act == 0ull) continue;
-            const uint32_t first = (uint32_t)__ffsll((long long)act) - 1u;
-#pragma unroll
-            for (int p = 0; p < OS_MAX_PASSES; ++p) {
-                if (p >= passes) break;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const uint32_t d = (kv[c] >> (8 * p)) & 255u;
-                    // skewed digits (e.g. the exponent byte of depth keys) would serialise LDS atomics: one add per wave when uniform
-                    const uint32_t d0 = __shfl(d, (int)first, 64);
-                    const bool uni = __ballot(in[u] && d == d0) == act;
-                    if (uni) { if (lane == first) atomicAdd(&h[p][d0], (uint32_t)__popcll(act)); }
-                    else if (in[u]) atomicAdd(&h[p][d], 1u);
-                }
-            }
+            os_hist_add(h, kk[u].x, in[u], passes); os_hist_add(h, kk[u].y, in[u], passes);
+            os_hist_add(h, kk[u].z, in[u], passes); os_hist_add(h, kk[u].w, in[u], passes);
         }
     }
-    if (blockIdx.x == 0 && tid < (n & 3u)) {                                                 // tail keys
-        const uint32_t k = keys[nvec * 4u + tid];
-        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(k >> (8 * p)) & 255u], 1u);
-    }
+    if (blockIdx.x == 0) { const bool in = tid < (n & 3u); os_hist_add(h, in ? keys[nvec * 4u + tid] : 0u, in, passes); }      // tail keys
     __syncthreads();
-    for (int p = 0; p < passes; ++p) { const uint32_t v = h[p][tid]; if (v) atomicAdd(&ghist[p * 256 + tid], v); }
+    os_hist_flush(h, ghist, passes, tid);
 }
 
 // Which passes are live, and which buffers pass `p` reads and writes.  Returns false when pass p is skipped.
-__device__ __forceinline__ bool os_schedule(const uint32_t* s_live /* [4] 0/1 */, int passes, int p, int& src, int& dst) {
-    int k = 0, j = 0;
-    for (int q = 0; q < passes; ++q) { if (s_live[q]) { if (q < p) ++j; ++k; } }
+// A single live pass would end in a scratch buffer: one identity pass is then run as well (a stable copy), so the number of
+// executed passes is 0, 2, 3 or 4 and the result always lands in buffer 0.
+__device__ __forceinline__ bool os_schedule(uint32_t* s_live /* [4] 0/1, may be amended */, int passes, int p, int& src, int& dst) {
+    int k = 0;
+    for (int q = 0; q < passes; ++q) k += s_live[q] ? 1 : 0;
+    if (k == 1) { for (int q = 0; q < passes; ++q) if (!s_live[q]) { s_live[q] = 1u; ++k; break; } }   // every thread writes the same value
+    int j = 0;
+    for (int q = 0; q < p; ++q) j += s_live[q] ? 1 : 0;
     if (!s_live[p]) return false;
-    // buffer sequence ending in buffer 0: even k: 0,1,0,1,...  odd k >= 3: 0,1,2,0,1,0,...  k == 1: 0 -> 1 (copied back afterwards)
-    auto buf_at = [k](int i) { if (k & 1) { if (k == 1) return i; if (i <= 2) return i; return (i - 3) & 1; } return i & 1; };
+    // buffer after i executed passes: even k: 0,1,0,1,...   odd k (>= 3): 0,1,2,0,1,0,...
+    auto buf_at = [k](int i) { if (k & 1) { if (i <= 2) return i; return (i - 3) & 1; } return i & 1; };
     src = buf_at(j);
     dst = buf_at(j + 1);
     return true;
 }
 
-// Batched descending look-back over rows hi, hi-1, ..., lo of a [row][256] status array for digit `tid`.  Adds the values of the
-// rows visited to `sum`; stops early (returns true) at a row flagged INCL.  Up to LB loads are in flight together, so a batch
-// costs one memory round trip; an unpublished row is polled alone (bounded) before the walk resumes.
+// ---- look-back words ----
+// tile level : 32-bit {epoch:18, count:14}: the tile's count of one digit (<= TILE_KEYS < 2^14).  Published once per launch.
+// group level: 64-bit {epoch:30, flag:2, value:32}: AGG = total of the group's tiles, INCL = inclusive global prefix at its end.
+// Small words matter: with every tile of a 10^6-key sort in flight at once, look-back reads are (tiles^2/group) KB of uncached
+// traffic per pass — as many bytes as the keys themselves if the words are wide or the tiles small.
+__device__ __forceinline__ uint32_t os_tword(uint32_t epoch, uint32_t count) { return ((epoch & 0x3FFFFu) << 14) | count; }
+__device__ __forceinline__ bool os_tpublished(uint32_t w, uint32_t epoch) { return (w >> 14) == (epoch & 0x3FFFFu); }
+
+// Sum of the tile-level counts of rows hi, hi-1, ..., lo (all must be published; at most LB rows) for digit `tid`.
 template <int LB>
-__device__ __forceinline__ bool os_lookback(const uint32_t* st, int32_t hi, int32_t lo, uint32_t tid, uint32_t& sum, uint32_t* err) {
-    int32_t t = hi;
-    uint32_t spins = 0;
-    while (t >= lo) {
+__device__ __forceinline__ uint32_t os_sum_tiles(const uint32_t* st, int32_t hi, int32_t lo, uint32_t tid, uint32_t epoch, uint32_t* err) {
+    uint32_t sum = 0, spins = 0;
+    int k0 = 0;
+    while (true) {
         uint32_t sv[LB];
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
-            const int32_t tt = t - k;
-            sv[k] = tt >= lo ? __hip_atomic_load(st + (size_t)tt * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            const int32_t tt = hi - k;
+            sv[k] = (k >= k0 && tt >= lo) ? __hip_atomic_load(st + (size_t)tt * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         }
-        int used = 0;
-        bool incl = false;
+        bool retry = false;
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
-            if (incl || used != k || t - k < lo) continue;
-            const uint32_t f = sv[k] >> 30;
-            if (f == 0u) continue;                                // not published yet
-            sum += sv[k] & OS_VAL_MASK;
-            used = k + 1;
-            if (f != 1u) incl = true;
+            if (retry || k < k0 || hi - k < lo) continue;
+            if (!os_tpublished(sv[k], epoch)) { k0 = k; retry = true; continue; }
+            sum += sv[k] & 0x3FFFu;
         }
-        if (incl) return true;
-        t -= used;
-        if (t >= lo && used < LB) {                               // row t is unpublished: poll that one word
-            const uint32_t* p = st + (size_t)t * 256u + tid;
-            while ((__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 30) == 0u) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 21)) { atomicExch(err, 1u); return true; }
-            }
-        }
+        if (!retry) return sum;
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return sum; }
     }
-    return false;
 }
 
-template <int ITEMS>
-__global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
-                                                        const uint32_t* __restrict__ ghist /* [4][256] */,
-                                                        uint32_t* status /* [tiles][256] of this pass, zeroed */, uint32_t* gstatus /* [groups][256], zeroed */, uint32_t* err, int dbg, unsigned long long* stamps) {
-    constexpr uint32_t TILE_KEYS = RS_THREADS * ITEMS;
+// Descending look-back over group words hi..0 for digit `tid`: adds values until a word flagged INCL (or the start).
+template <int LB>
+__device__ __forceinline__ uint32_t os_sum_groups(const u64* st, int32_t hi, uint32_t tid, uint32_t epoch, uint32_t* err) {
+    uint32_t sum = 0, spins = 0;
+    for (int32_t t = hi; t >= 0; t -= LB) {
+        int k0 = 0;
+        while (true) {
+            u64 sv[LB];
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                const int32_t tt = t - k;
+                sv[k] = (k >= k0 && tt >= 0) ? __hip_atomic_load(st + (size_t)tt * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+            bool retry = false;
+#pragma unroll
+            for (int k = 0; k < LB; ++k) {
+                if (retry || k < k0 || t - k < 0) continue;
+                const uint32_t f = os_flag(sv[k], epoch);
+                if (f == 0u) { k0 = k; retry = true; continue; }
+                sum += (uint32_t)sv[k];
+                if (f == 2u) return sum;
+            }
+            if (!retry) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return sum; }
+        }
+    }
+    return sum;
+}
+
+// exclusive scan of one value per digit (threads 0..255 carry a value, all THREADS threads take part in the barriers)
+template <int THREADS>
+__device__ __forceinline__ uint32_t digit_excl_scan(uint32_t v, uint32_t* tmp /* __shared__[4] */, uint32_t tid) {
+    const uint32_t lane = tid & 63u, w = tid >> 6;
+    const uint32_t inc = wave_incl_scan_u32(tid < 256u ? v : 0u, lane);
+    __syncthreads();
+    if (lane == 63u && w < 4u) tmp[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if ((unsigned)k < w) base += tmp[k];
+    return base + inc - v;
+}
+
+template <int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
+                                                     const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
+                                                     uint32_t* status /* [tiles][256] */, u64* gstatus /* [groups][256] */, uint32_t epoch, uint32_t* err,
+                                                     u64* stamps /* tuning aid, may be null */) {
+    constexpr uint32_t TILE_KEYS = THREADS * ITEMS;
+    constexpr int WAVES = THREADS / 64;
+    static_assert(TILE_KEYS < (1u << 14), "tile-level look-back words carry 14-bit counts");
     __shared__ uint32_t skeys[TILE_KEYS];
     __shared__ uint32_t svals[TILE_KEYS];
-    __shared__ uint32_t wcnt[RS_WAVES][256];
+    __shared__ uint32_t wcnt[WAVES][256];
     __shared__ uint32_t loff[256];      // first local slot of digit d in the reordered tile
     __shared__ uint32_t gpos[256];      // global slot of that first element
     __shared__ uint32_t s_tmp[4];
@@ -221,15 +243,23 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const uint32_t tile = blockIdx.x;
     const uint32_t ntiles = (n + TILE_KEYS - 1u) / TILE_KEYS;
+    if (pass == 0 && tile == 0) { for (uint32_t q = tid; q < OS_SLOT_WORDS; q += THREADS) ghist_other[q] = 0u; }   // the histogram slot of the NEXT sort
     if (tile >= ntiles) return;                                   // uniform
     if (stamps && tid == 0) stamps[tile * 8 + 0] = wall_clock64();
     const int shift = 8 * pass;
     if (tid < OS_MAX_PASSES) s_live[tid] = 1u;
-#pragma unroll
-    for (int k = 0; k < RS_WAVES; ++k) wcnt[k][tid] = 0;
+    for (uint32_t q = tid; q < WAVES * 256u; q += THREADS) (&wcnt[0][0])[q] = 0u;
     __syncthreads();
     uint32_t tot = 0;
-    for (int q = 0; q < passes; ++q) { const uint32_t g = ghist[q * 256 + tid]; if (q == pass) tot = g; if (g == n) s_live[q] = 0u; }   // one digit holds every key
+    if (tid < 256u) {
+        for (int q = 0; q < passes; ++q) {
+            uint32_t g = 0;
+#pragma unroll
+            for (int r = 0; r < OS_REPL; ++r) g += ghist[(r * OS_MAX_PASSES + q) * 256 + tid];
+            if (q == pass) tot = g;
+            if (g == n) s_live[q] = 0u;                           // one digit holds every key
+        }
+    }
     __syncthreads();
     int src, dst;
     if (!os_schedule(s_live, passes, pass, src, dst)) return;    // uniform: this pass is an identity
@@ -246,8 +276,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
         key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
         val[j] = valid ? vals_in[i] : 0u;
     }
-    const uint32_t digit_base = block_excl_scan_256(tot, s_tmp, tid);          // overlaps the loads above
-    if (stamps && tid == 0) { stamps[tile * 8 + 1] = wall_clock64(); stamps[tile * 8 + 6] = key[0]; }
+    const uint32_t digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid);     // overlaps the loads above
+    if (stamps && tid == 0) stamps[tile * 8 + 1] = wall_clock64();
 
     const uint64_t lt = (1ull << lane) - 1ull;
     volatile uint32_t* wc = wcnt[w];
@@ -272,50 +302,45 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // thread d: counts per wave -> offsets inside the tile's digit-d run; tile count of digit d
+    // thread d: counts per wave -> offsets inside the tile's digit-d run; tile count of digit d; publish it at once
     uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 0; k < RS_WAVES; ++k) { const uint32_t t = wcnt[k][tid]; wcnt[k][tid] = cnt; cnt += t; }
-    if (stamps && tid == 0) stamps[tile * 8 + 2] = wall_clock64();
-    // Publish, then look back — two levels, so that the walk costs ~3 memory round trips however many tiles start together:
-    // tiles in groups of OS_GROUP; the last tile of a group also publishes the group's aggregate / inclusive prefix.
-    uint32_t* my = status + (size_t)tile * 256u + tid;
     const uint32_t grp = tile / OS_GROUP;
     const bool last_in_group = (tile % OS_GROUP) == OS_GROUP - 1u;
-    uint32_t prefix = 0;
-    if (tile == 0 || (dbg & 2)) {
-        __hip_atomic_store(my, OS_FLAG_INCL | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        __hip_atomic_store(my, OS_FLAG_AGG | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool full = os_lookback<16>(status, (int32_t)tile - 1, (int32_t)(grp * OS_GROUP), tid, prefix, err);
-        if (!full) {                                              // reached the start of the group: need the groups before it
-            if (last_in_group) __hip_atomic_store(gstatus + (size_t)grp * 256u + tid, OS_FLAG_AGG | ((prefix + cnt) & OS_VAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)os_lookback<16>(gstatus, (int32_t)grp - 1, 0, tid, prefix, err);
-        }
-        __hip_atomic_store(my, OS_FLAG_INCL | ((prefix + cnt) & OS_VAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 256u) {
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) { const uint32_t t = wcnt[k][tid]; wcnt[k][tid] = cnt; cnt += t; }
+        __hip_atomic_store(status + (size_t)tile * 256u + tid, os_tword(epoch, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (last_in_group) __hip_atomic_store(gstatus + (size_t)grp * 256u + tid, OS_FLAG_INCL | ((prefix + cnt) & OS_VAL_MASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (stamps && tid == 0) stamps[tile * 8 + 3] = wall_clock64();
-    // exclusive scan of the tile's digit counts -> local run starts
-    loff[tid] = block_excl_scan_256(cnt, s_tmp, tid);
-    gpos[tid] = digit_base + prefix;
+    if (stamps && tid == 0) stamps[tile * 8 + 2] = wall_clock64();
+    // local run starts, then the reorder inside LDS — none of it needs the other tiles, so it overlaps their publishing
+    const uint32_t lo_ = digit_excl_scan<THREADS>(cnt, s_tmp, tid);
+    if (tid < 256u) loff[tid] = lo_;
     __syncthreads();
-    // reorder inside LDS: stable (wave-major, item-major, lane order == memory order)
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        if ((wbase + j * 64u + lane) < n) {
+        if ((wbase + j * 64u + lane) < n) {                       // stable: wave-major, item-major, lane order == memory order
             const uint32_t d = (key[j] >> shift) & 255u;
             const uint32_t l = loff[d] + wcnt[w][d] + rank[j];
             skeys[l] = key[j];
             svals[l] = val[j];
         }
     }
+    if (stamps && tid == 0) stamps[tile * 8 + 3] = wall_clock64();
+    // look back: the tiles of this group before this one, then the groups before this group
+    if (tid < 256u) {
+        uint32_t prefix = 0;
+        if (tile > grp * OS_GROUP) prefix = os_sum_tiles<(int)OS_GROUP>(status, (int32_t)tile - 1, (int32_t)(grp * OS_GROUP), tid, epoch, err);
+        if (last_in_group && grp > 0) __hip_atomic_store(gstatus + (size_t)grp * 256u + tid, os_word(epoch, OS_AGG, prefix + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (grp > 0) prefix += os_sum_groups<16>(gstatus, (int32_t)grp - 1, tid, epoch, err);
+        if (last_in_group) __hip_atomic_store(gstatus + (size_t)grp * 256u + tid, os_word(epoch, OS_INCL, prefix + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gpos[tid] = digit_base + prefix;
+    }
     __syncthreads();
     if (stamps && tid == 0) stamps[tile * 8 + 4] = wall_clock64();
     const uint32_t tcount = min(TILE_KEYS, n - tbase);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t l = j * RS_THREADS + tid;
+        const uint32_t l = j * THREADS + tid;
         if (l < tcount) {
             const uint32_t k = skeys[l];
             const uint32_t d = (k >> shift) & 255u;
@@ -327,20 +352,6 @@ __global__ __launch_bounds__(RS_THREADS) void k_os_pass(OsBufs bufs, uint32_t n_
     if (stamps && tid == 0) stamps[tile * 8 + 5] = wall_clock64();
 }
 
-// Exactly one live pass leaves the result in scratch buffer 1: copy it back (device-side decision; otherwise a no-op launch).
-__global__ __launch_bounds__(256) void k_os_copyback(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int passes, const uint32_t* __restrict__ ghist) {
-    __shared__ uint32_t s_live[OS_MAX_PASSES];
-    const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
-    if (threadIdx.x < OS_MAX_PASSES) s_live[threadIdx.x] = 1u;
-    __syncthreads();
-    for (int q = 0; q < passes; ++q) if (ghist[q * 256 + threadIdx.x] == n) s_live[q] = 0u;
-    __syncthreads();
-    int k = 0;
-    for (int q = 0; q < passes; ++q) k += s_live[q] ? 1 : 0;
-    if (k != 1) return;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { bufs.k[0][i] = bufs.k[1][i]; bufs.v[0][i] = bufs.v[1][i]; }
-}
-
 hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n) {
     hipError_t e;
     if (s.cap < n) {
@@ -350,16 +361,19 @@ hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n) {
         s.vals2 = s.keys2 + 2 * n;
         s.cap = n;
     }
-    // control block: [ghist A 4x256][ghist B 4x256] then status [4 passes][tiles][256]
+    // control block: two [OS_REPL][4][256] histogram slots (alternating), then the 64-bit look-back words [tiles + groups][256]
     const size_t tiles = (n + 1023) / 1024;          // smallest tile = 1024 keys
-    const size_t words = 2 * 4 * 256 + (size_t)OS_MAX_PASSES * (tiles + tiles / OS_GROUP + 1) * 256;
+    const size_t words = 2 * OS_SLOT_WORDS + (tiles + 2 * (tiles / OS_GROUP + 2)) * 256;
     if (s.hist_cap < words) {
-        if (s.hist) { (void)hipStreamSynchronize(st); (void)hipFree(s.hist); }
-        s.hist = nullptr; s.hist_cap = 0;
-        if ((e = hipMalloc(&s.hist, words * 4)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(s.hist, 0, 2 * 4 * 256 * 4, st)) != hipSuccess) return e;     // both histograms start zero; each sort re-zeroes the other one
-        s.hist_cap = words;
-        s.flip = 0;
+        uint32_t* nh = nullptr;
+        if ((e = hipMalloc(&nh, words * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(nh, 0, words * 4, st)) != hipSuccess) return e;
+        if (s.hist) {
+            // keep a histogram that a producer kernel has already accumulated into the current slot
+            if ((e = hipMemcpyAsync(nh, s.hist, 2 * OS_SLOT_WORDS * 4, hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+            (void)hipStreamSynchronize(st); (void)hipFree(s.hist);
+        }
+        s.hist = nh; s.hist_cap = words;
     }
     if (!s.totals) { if ((e = hipMalloc(&s.totals, 256 * 4)) != hipSuccess) return e; if ((e = hipMemsetAsync(s.totals, 0, 1024, st)) != hipSuccess) return e; }
     return hipSuccess;
@@ -372,52 +386,78 @@ void sort_scratch_free(SortScratch& s) {
     s = SortScratch();
 }
 
-template <int ITEMS>
-static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes) {
-    static const int dbgk = getenv("GS4D_SORT_DBG") ? atoi(getenv("GS4D_SORT_DBG")) : 0;
-    static const char* stampf = getenv("GS4D_SORT_STAMP_FILE");
-    unsigned long long* stamps = nullptr;
-    if (stampf) { if (hipMalloc(&stamps, (size_t)((n + RS_THREADS * ITEMS - 1) / (RS_THREADS * ITEMS)) * 64) != hipSuccess) stamps = nullptr; }
-    const uint32_t tile_keys = RS_THREADS * ITEMS;
+uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out) {
+    // The slot a producer kernel (k_keygen, k_bin_emit) accumulates the digit histograms of the NEXT sort into.  It is zero unless an
+    // earlier producer's histogram was never consumed by a sort; then it is cleared first.
+    hipError_t e = sort_scratch_reserve(st, s, n_hint);
+    if (e == hipSuccess && s.hist_pending) e = hipMemsetAsync(s.hist + (s.flip ? OS_SLOT_WORDS : 0), 0, OS_SLOT_WORDS * 4, st);
+    if (e_out) *e_out = e;
+    if (e != hipSuccess) return nullptr;
+    s.hist_pending = true;
+    return s.hist + (s.flip ? OS_SLOT_WORDS : 0);
+}
+
+template <int THREADS, int ITEMS>
+static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist) {
+    const uint32_t tile_keys = THREADS * ITEMS;
     const uint32_t tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
-    uint32_t* ghist = s.hist + (s.flip ? 1024 : 0);
-    uint32_t* ghist_next = s.hist + (s.flip ? 0 : 1024);
+    uint32_t* ghist = s.hist + (s.flip ? OS_SLOT_WORDS : 0);
+    uint32_t* ghist_other = s.hist + (s.flip ? 0 : OS_SLOT_WORDS);
+    hipError_t e;
+    if (!have_hist) {
+        if (s.hist_pending) { if ((e = hipMemsetAsync(ghist, 0, OS_SLOT_WORDS * 4, st)) != hipSuccess) return e; }   // someone else's histogram sits in the slot
+        const uint32_t hist_blocks = (uint32_t)std::min<size_t>((n / 16 + 255) / 256 + 1, 256);          // few workgroups: each flushes 256 global atomics per pass
+        k_os_hist<<<dim3(hist_blocks), dim3(256), 0, st>>>(keys, (uint32_t)n, n_dev, passes, ghist);
+    }
+    s.hist_pending = false;
     s.flip ^= 1;
-    uint32_t* status = s.hist + 2048;
-    const uint32_t groups = tiles / OS_GROUP + 1;
-    const size_t per_pass = (size_t)(tiles + groups) * 256;
-    const uint32_t status_words = (uint32_t)((size_t)passes * per_pass);
+    static const char* stampf = getenv("GS4D_SORT_STAMP_FILE");
+    static const int stamp_pass = getenv("GS4D_SORT_STAMP_PASS") ? atoi(getenv("GS4D_SORT_STAMP_PASS")) : 0;
+    u64* stamps = nullptr;
+    if (stampf && hipMalloc(&stamps, (size_t)tiles * 64) != hipSuccess) stamps = nullptr;
+    uint32_t* status = s.hist + 2 * OS_SLOT_WORDS;
+    u64* gstatus = reinterpret_cast<u64*>(status + (((size_t)tiles * 256 + 1) & ~(size_t)1));
     OsBufs b;
     b.k[0] = keys; b.v[0] = vals;
     b.k[1] = s.keys2; b.v[1] = s.vals2;
     b.k[2] = s.keys2 + s.cap; b.v[2] = s.vals2 + s.cap;
-    const uint32_t hist_blocks = (uint32_t)std::min<size_t>((n / 16 + 255) / 256 + 1, 256);      // few workgroups: each flushes 256 global atomics per pass
-    k_os_hist<<<dim3(hist_blocks), dim3(256), 0, st>>>(keys, (uint32_t)n, n_dev, passes, ghist, ghist_next, status, status_words);
-    for (int p = 0; p < passes; ++p)
-        k_os_pass<ITEMS><<<dim3(tiles), dim3(RS_THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, status + p * per_pass, status + p * per_pass + (size_t)tiles * 256, s.err ? s.err : s.totals, dbgk, (stampf && p == 0) ? stamps : nullptr);
-    k_os_copyback<<<dim3(512), dim3(256), 0, st>>>(b, (uint32_t)n, n_dev, passes, ghist);
-    if (stampf) {   // debugging aid: dump per-tile wall-clock stamps (100 MHz) of pass 0
+    for (int p = 0; p < passes; ++p) {
+        ++s.epoch;
+        if ((s.epoch & 0x3FFFFu) == 0u) {    // the 18-bit tile-level epoch wraps: forget every old word
+            if ((e = hipMemsetAsync(status, 0, (s.hist_cap - 2 * OS_SLOT_WORDS) * 4, st)) != hipSuccess) return e;
+            ++s.epoch;
+        }
+        k_os_pass<THREADS, ITEMS><<<dim3(tiles), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, gstatus, s.epoch & 0x3FFFFFFFu,
+                                                                         s.err ? s.err : s.totals, (stampf && p == stamp_pass) ? stamps : nullptr);
+    }
+    if (stampf && stamps) {   // tuning aid: dump per-tile wall-clock stamps (100 MHz) of one pass
         (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)tiles * 8);
-        (void)hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<u64> hs((size_t)tiles * 8);
+        (void)hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
         FILE* f = fopen(stampf, "w");
-        if (f) { for (uint32_t t = 0; t < tiles; ++t) { for (int k = 0; k < 6; ++k) fprintf(f, "%llu ", h[t * 8 + k] - h[0]); fprintf(f, "\n"); } fclose(f); }
+        if (f) { for (uint32_t t = 0; t < tiles; ++t) { for (int k = 0; k < 6; ++k) fprintf(f, "%llu ", hs[t * 8 + k] - hs[0]); fprintf(f, "\n"); } fclose(f); }
         (void)hipFree(stamps);
     }
     return hipGetLastError();
 }
 
-hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits) {
+hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist) {
     if (n <= 1) return hipSuccess;                    // radix_sort.hpp:260
-    if (n >= (1u << 30)) return hipErrorInvalidValue;  // status words carry 30-bit counts
+    if (n >= (1ull << 32) - 1) return hipErrorInvalidValue;
     hipError_t e = sort_scratch_reserve(st, s, n);
     if (e != hipSuccess) return e;
-    const int passes = (key_bits + 7) / 8;
-    static const int knob = getenv("GS4D_SORT_ITEMS") ? atoi(getenv("GS4D_SORT_ITEMS")) : 0;      // tuning knob (experiments only)
-    const int items = knob ? knob : (n <= ((size_t)4 << 20) ? 8 : 16);
-    if (items == 4) return onesweep<4>(st, s, keys, vals, n, n_dev, passes);
-    if (items == 8) return onesweep<8>(st, s, keys, vals, n, n_dev, passes);
-    return onesweep<16>(st, s, keys, vals, n, n_dev, passes);
+    int passes = (key_bits + 7) / 8;
+    if (passes < 2) passes = 2;                       // an even number of executed passes always exists (see os_schedule)
+    static const int knob = getenv("GS4D_SORT_SHAPE") ? atoi(getenv("GS4D_SORT_SHAPE")) : 0;      // tuning knob (experiments only)
+    const int shape = knob ? knob : (n <= ((size_t)3 << 20) ? 2 : 5);     // 4096-key tiles for small sorts, 8192-key tiles beyond
+    switch (shape) {
+    case 1: return onesweep<256, 8>(st, s, keys, vals, n, n_dev, passes, have_hist);
+    case 2: return onesweep<512, 8>(st, s, keys, vals, n, n_dev, passes, have_hist);
+    case 3: return onesweep<1024, 8>(st, s, keys, vals, n, n_dev, passes, have_hist);
+    case 4: return onesweep<256, 16>(st, s, keys, vals, n, n_dev, passes, have_hist);
+    case 5: return onesweep<512, 16>(st, s, keys, vals, n, n_dev, passes, have_hist);
+    default: return onesweep<512, 4>(st, s, keys, vals, n, n_dev, passes, have_hist);
+    }
 }
 
 } // namespace gs4d

@@ -22,6 +22,7 @@ pk0, _ = ctx.device_ptr(kb0); pv0, _ = ctx.device_ptr(vb0); pk, _ = ctx.device_p
 def reset():
     hip.hipMemcpy(C.c_void_p(pk), C.c_void_p(pk0), C.c_size_t(4 * n), 3)
     hip.hipMemcpy(C.c_void_p(pv), C.c_void_p(pv0), C.c_size_t(4 * n), 3)
+    hip.hipDeviceSynchronize()
 for _ in range(5):
     reset(); ctx.sort_pairs(kb, vb, n)
 ctx.finish()
