@@ -47,6 +47,8 @@ struct gs4d_ctx {
     int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
     hipStream_t st = nullptr;          // stream in use (own_st unless the caller supplied one)
     hipStream_t own_st = nullptr;
+    hipStream_t st2 = nullptr;         // side stream: the preprocess of a draw runs here, beside the depth sort queued on `st`
+    hipEvent_t ev_draw_done = nullptr, ev_soa = nullptr, ev_pre_done = nullptr;
     std::string err;
     std::vector<Buffer> bufs;          // index = name; bufs[0] unused
     gs4d_buf slots[8] = { 0 };
@@ -91,22 +93,23 @@ int hipfail(gs4d_ctx* c, hipError_t e, const char* where) {
 Buffer* getbuf(gs4d_ctx* c, gs4d_buf b) { return (b != 0 && b < c->bufs.size() && c->bufs[b].alive) ? &c->bufs[b] : nullptr; }
 
 struct StageTimer {
-    gs4d_ctx* c; int slot;
-    StageTimer(gs4d_ctx* c_, int id) : c(c_), slot(-1) {
-        if (((c->profiling >> id) & 1u) && c->prof_frame < gs4d_ctx::PROF_FRAMES) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], c->st); }
+    gs4d_ctx* c; int slot; hipStream_t s;
+    StageTimer(gs4d_ctx* c_, int id, hipStream_t stream = nullptr) : c(c_), slot(-1), s(stream ? stream : c_->st) {
+        if (((c->profiling >> id) & 1u) && c->prof_frame < gs4d_ctx::PROF_FRAMES) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], s); }
     }
-    ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(c->ev1[slot], c->st); c->ran[slot] = 1; } }
+    ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(c->ev1[slot], s); c->ran[slot] = 1; } }
 };
 
 int ensure_soa(gs4d_ctx* c, Buffer& b) {
     const size_t n = b.bytes / 96;
     if (b.soa && b.soa_n == n && b.soa_version == b.version) return GS4D_OK;
     if (!b.soa || b.soa_n != n) {
-        if (b.soa) { HIPCHK(c, hipStreamSynchronize(c->st)); (void)hipFree(b.soa); b.soa = nullptr; }
+        if (b.soa) { HIPCHK(c, hipStreamSynchronize(c->st)); HIPCHK(c, hipStreamSynchronize(c->st2)); (void)hipFree(b.soa); b.soa = nullptr; }
         if (n) HIPCHK(c, hipMalloc(&b.soa, n * 96));
         b.soa_n = n;
     }
     HIPCHK(c, launch_soa_repack(c->st, (const float*)b.d, n, b.soa));
+    HIPCHK(c, hipEventRecord(c->ev_soa, c->st));
     b.soa_version = b.version;
     return GS4D_OK;
 }
@@ -147,6 +150,7 @@ int enqueue_raster(gs4d_ctx* c, const uint32_t* order, size_t ninst, size_t nrec
         HIPCHK(c, launch_composite(c->st, c->proj, c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
     }
     HIPCHK(c, hipEventRecord(c->pending_ev, c->st));       // the last binning workgroup wrote the total straight into pinned host memory
+    HIPCHK(c, hipEventRecord(c->ev_draw_done, c->st));
     return GS4D_OK;
 }
 
@@ -173,6 +177,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (preprocess) {
         if (c->proj_cap < npre) {
             HIPCHK(c, hipStreamSynchronize(c->st));
+            HIPCHK(c, hipStreamSynchronize(c->st2));
             if (c->proj) (void)hipFree(c->proj);
             if (c->rects) (void)hipFree(c->rects);
             c->proj = nullptr; c->rects = nullptr; c->proj_cap = 0;
@@ -181,11 +186,20 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             c->proj_cap = npre;
         }
         if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
-        StageTimer t(c, GS4D_T_PREPROCESS);
-        const PreOut po = { c->proj, c->rects, c->bin.ranges, (uint32_t)c->bin.zero_words() };
-        if (a.quads) HIPCHK(c, launch_preprocess_3d(c->st, (const float*)data->d, npre, a.u, c->W, c->H, po));
-        else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->st, (const float*)data->d, npre, a.u, c->W, c->H, po));
-        else HIPCHK(c, launch_preprocess_4d(c->st, data->soa, npre, a.u, c->W, c->H, po));
+        // The projection does not depend on the sort: it runs on the side stream, beside the key generation / depth sort that the
+        // caller queued on `st` for this frame.  It needs only the previous draw to be finished (it reuses that draw's projected
+        // records and binning control block) and the SoA shadow of the records.
+        HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_draw_done, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_soa, 0));
+        {
+            StageTimer t(c, GS4D_T_PREPROCESS, c->st2);
+            const PreOut po = { c->proj, c->rects, c->bin.ranges, (uint32_t)c->bin.zero_words() };
+            if (a.quads) HIPCHK(c, launch_preprocess_3d(c->st2, (const float*)data->d, npre, a.u, c->W, c->H, po));
+            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->st2, (const float*)data->d, npre, a.u, c->W, c->H, po));
+            else HIPCHK(c, launch_preprocess_4d(c->st2, data->soa, npre, a.u, c->W, c->H, po));
+        }
+        HIPCHK(c, hipEventRecord(c->ev_pre_done, c->st2));
+        HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_pre_done, 0));
         c->proj_n = npre;
     }
     size_t want = a.instances * 2 + 65536;
@@ -258,6 +272,11 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
     c->st = c->own_st;
     if ((e = hipEventCreateWithFlags(&c->pending_ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
+    if ((e = hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
+    for (hipEvent_t* ev : { &c->ev_draw_done, &c->ev_soa, &c->ev_pre_done }) {
+        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
+        if ((e = hipEventRecord(*ev, c->st)) != hipSuccess) return bail(hipfail(c, e, "hipEventRecord"));      // "already happened"
+    }
     if ((e = hipHostMalloc((void**)&c->host_total, 64, hipHostMallocMapped)) != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
     memset(c->host_total, 0, 64);
     if ((e = hipHostGetDevicePointer((void**)&c->host_total_dev, c->host_total, 0)) != hipSuccess) return bail(hipfail(c, e, "hipHostGetDevicePointer"));
@@ -273,6 +292,7 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
+    if (c->st2) (void)hipStreamSynchronize(c->st2);
     for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); }
     if (c->fb) (void)hipFree(c->fb);
     if (c->proj) (void)hipFree(c->proj);
@@ -284,6 +304,8 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (c->pending_ev) (void)hipEventDestroy(c->pending_ev);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t ev : { c->ev_draw_done, c->ev_soa, c->ev_pre_done }) if (ev) (void)hipEventDestroy(ev);
+    if (c->st2) (void)hipStreamDestroy(c->st2);
     if (c->own_st) (void)hipStreamDestroy(c->own_st);
     delete c;
 }
