@@ -65,7 +65,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t ninst, uint32_t nrecords,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
                                                           unsigned long long* status, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
                                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
                                                           uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host) {
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
         r[j] = Rect{ 0, 0, 0, 0, 0 }; rec[j] = 0;
         if (k < ninst) {
             rec[j] = order ? order[k] : k;
+            if (order_copy) order_copy[k] = rec[j];      // the draw keeps its own copy: the caller may refill the buffer for the next frame
             if (rec[j] < nrecords) {              // an index past the bound SSBO: GL would read undefined data; we draw nothing
                 const uint2 rr = rects[rec[j]];
                 const uint32_t x0 = rr.x & 0xFFFFu, y0 = rr.x >> 16, x1 = rr.y & 0xFFFFu, y1 = rr.y >> 16;
@@ -199,11 +200,11 @@ void bin_scratch_free(BinScratch& b) {
     b = BinScratch();
 }
 
-hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
+hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
                           uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host) {
     (void)tiles_y;
     const uint32_t nb = (uint32_t)((ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host);
+    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host);
     return hipGetLastError();
 }
 

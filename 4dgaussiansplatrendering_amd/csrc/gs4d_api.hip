@@ -47,8 +47,17 @@ struct gs4d_ctx {
     int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
     hipStream_t st = nullptr;          // stream in use (own_st unless the caller supplied one)
     hipStream_t own_st = nullptr;
-    hipStream_t st2 = nullptr;         // side stream: the preprocess of a draw runs here, beside the depth sort queued on `st`
-    hipEvent_t ev_draw_done = nullptr, ev_soa = nullptr, ev_pre_done = nullptr;
+    // Two streams.  `st` (the caller-visible one) carries the ORDER stage of a frame: SoA refresh, key generation, depth sort.
+    // `rs` carries the RASTER stage: preprocess, tile binning, tile sort, composite, read-back.  The raster stage of frame f and the
+    // order stage of frame f+1 touch disjoint data (the draw keeps a private copy of the sort index it was given), so consecutive
+    // frames overlap on the GPU; the events below carry the few true dependencies.
+    hipStream_t rs = nullptr;
+    hipEvent_t ev_soa = nullptr;          // st: SoA shadow rebuilt                          -> rs waits before preprocess
+    hipEvent_t ev_order_ready = nullptr;  // st: everything queued before the draw call      -> rs waits before binning reads the sort index
+    hipEvent_t ev_emit_done = nullptr;    // rs: binning has read (and copied) the sort index -> st waits before overwriting that buffer
+    hipEvent_t ev_readback = nullptr;     // rs: device-side read-back enqueued               -> st waits so the caller's stream sees it
+    uint32_t* order_copy = nullptr; size_t order_cap = 0;   // private copy of the last draw's sort index (for a re-run after overflow)
+    gs4d_buf last_order = 0;              // buffer the in-flight draw read its sort index from
     std::string err;
     std::vector<Buffer> bufs;          // index = name; bufs[0] unused
     gs4d_buf slots[8] = { 0 };
@@ -67,7 +76,6 @@ struct gs4d_ctx {
     uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
     uint32_t* dev_err = nullptr;       // = host_total_dev + 4
     gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
-    hipEvent_t pending_ev = nullptr;
     bool pending = false;
     DrawArgs pending_args;
     uint64_t stat_entries = 0, stat_reruns = 0;
@@ -100,11 +108,17 @@ struct StageTimer {
     ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(c->ev1[slot], s); c->ran[slot] = 1; } }
 };
 
+int sync_all(gs4d_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipStreamSynchronize(c->rs));
+    return GS4D_OK;
+}
+
 int ensure_soa(gs4d_ctx* c, Buffer& b) {
     const size_t n = b.bytes / 96;
     if (b.soa && b.soa_n == n && b.soa_version == b.version) return GS4D_OK;
     if (!b.soa || b.soa_n != n) {
-        if (b.soa) { HIPCHK(c, hipStreamSynchronize(c->st)); HIPCHK(c, hipStreamSynchronize(c->st2)); (void)hipFree(b.soa); b.soa = nullptr; }
+        if (b.soa) { int rc = sync_all(c); if (rc) return rc; (void)hipFree(b.soa); b.soa = nullptr; }
         if (n) HIPCHK(c, hipMalloc(&b.soa, n * 96));
         b.soa_n = n;
     }
@@ -116,7 +130,7 @@ int ensure_soa(gs4d_ctx* c, Buffer& b) {
 
 int ensure_pairs(gs4d_ctx* c, size_t cap) {
     if (c->pair_cap >= cap) return GS4D_OK;
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    { int rc = sync_all(c); if (rc) return rc; }
     if (c->pair_keys) (void)hipFree(c->pair_keys);
     if (c->pair_vals) (void)hipFree(c->pair_vals);
     c->pair_keys = c->pair_vals = nullptr; c->pair_cap = 0;
@@ -126,31 +140,30 @@ int ensure_pairs(gs4d_ctx* c, size_t cap) {
     return GS4D_OK;
 }
 
-// Enqueue binning -> tile sort -> ranges -> composite for projected records already in c->proj.
-int enqueue_raster(gs4d_ctx* c, const uint32_t* order, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, bool zeroed) {
+// Enqueue binning -> tile sort -> ranges -> composite on the raster stream for projected records already in c->proj.
+int enqueue_raster(gs4d_ctx* c, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, bool zeroed) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
     {
-        StageTimer t(c, GS4D_T_BINNING);
-        if (!zeroed) HIPCHK(c, hipMemsetAsync(c->bin.ranges, 0, c->bin.zero_words() * 4, c->st));      // re-run of a draw: preprocess did not run
+        StageTimer t(c, GS4D_T_BINNING, c->rs);
+        if (!zeroed) HIPCHK(c, hipMemsetAsync(c->bin.ranges, 0, c->bin.zero_words() * 4, c->rs));      // re-run of a draw: preprocess did not run
         hipError_t he = hipSuccess;
-        uint32_t* ph = sort_hist_slot(c->st, c->pair_sort, c->pair_cap, &he);      // the emit kernel also counts the tile-id digits
+        uint32_t* ph = sort_hist_slot(c->rs, c->pair_sort, c->pair_cap, &he);      // the emit kernel also counts the tile-id digits
         if (!ph) return hipfail(c, he, "sort_hist_slot");
-        HIPCHK(c, launch_binning(c->st, c->bin, c->rects, order, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err,
+        HIPCHK(c, launch_binning(c->rs, c->bin, c->rects, order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err,
                                  ph, tile_passes, c->host_total_dev));
     }
+    HIPCHK(c, hipEventRecord(c->ev_emit_done, c->rs));     // the last binning workgroup wrote the total straight into pinned host memory
     {
-        StageTimer t(c, GS4D_T_PAIRSORT);
-        HIPCHK(c, radix_sort_pairs(c->st, c->pair_sort, c->pair_keys, c->pair_vals, c->pair_cap, c->bin.total, tile_bits, true));
-        HIPCHK(c, launch_tile_ranges(c->st, c->bin, c->pair_keys, c->pair_cap, ntiles));
+        StageTimer t(c, GS4D_T_PAIRSORT, c->rs);
+        HIPCHK(c, radix_sort_pairs(c->rs, c->pair_sort, c->pair_keys, c->pair_vals, c->pair_cap, c->bin.total, tile_bits, true));
+        HIPCHK(c, launch_tile_ranges(c->rs, c->bin, c->pair_keys, c->pair_cap, ntiles));
     }
     {
-        StageTimer t(c, GS4D_T_COMPOSITE);
-        HIPCHK(c, launch_composite(c->st, c->proj, c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
+        StageTimer t(c, GS4D_T_COMPOSITE, c->rs);
+        HIPCHK(c, launch_composite(c->rs, c->proj, c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
     }
-    HIPCHK(c, hipEventRecord(c->pending_ev, c->st));       // the last binning workgroup wrote the total straight into pinned host memory
-    HIPCHK(c, hipEventRecord(c->ev_draw_done, c->st));
     return GS4D_OK;
 }
 
@@ -173,11 +186,22 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances == 0 || nrec == 0) return GS4D_OK;
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
-    HIPCHK(c, bin_scratch_reserve(c->st, c->bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
+    HIPCHK(c, bin_scratch_reserve(c->rs, c->bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
+    uint32_t* order_copy = nullptr;
+    if (order) {
+        if (c->order_cap < a.instances) {
+            int rc = sync_all(c); if (rc) return rc;
+            if (c->order_copy) (void)hipFree(c->order_copy);
+            c->order_copy = nullptr; c->order_cap = 0;
+            HIPCHK(c, hipMalloc(&c->order_copy, a.instances * 4));
+            c->order_cap = a.instances;
+        }
+        if (preprocess) order_copy = c->order_copy;       // first run: the emit kernel reads the caller's buffer and keeps a copy
+        else order = c->order_copy;                        // re-run: the caller's buffer may have been overwritten since
+    }
     if (preprocess) {
         if (c->proj_cap < npre) {
-            HIPCHK(c, hipStreamSynchronize(c->st));
-            HIPCHK(c, hipStreamSynchronize(c->st2));
+            int rc = sync_all(c); if (rc) return rc;
             if (c->proj) (void)hipFree(c->proj);
             if (c->rects) (void)hipFree(c->rects);
             c->proj = nullptr; c->rects = nullptr; c->proj_cap = 0;
@@ -186,26 +210,25 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             c->proj_cap = npre;
         }
         if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
-        // The projection does not depend on the sort: it runs on the side stream, beside the key generation / depth sort that the
-        // caller queued on `st` for this frame.  It needs only the previous draw to be finished (it reuses that draw's projected
-        // records and binning control block) and the SoA shadow of the records.
-        HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_draw_done, 0));
-        HIPCHK(c, hipStreamWaitEvent(c->st2, c->ev_soa, 0));
+        // The projection does not depend on the sort: on the raster stream it runs beside the key generation / depth sort that the
+        // caller queued on `st` for this frame (and follows the previous frame's composite, whose records it overwrites).
+        HIPCHK(c, hipStreamWaitEvent(c->rs, c->ev_soa, 0));
         {
-            StageTimer t(c, GS4D_T_PREPROCESS, c->st2);
+            StageTimer t(c, GS4D_T_PREPROCESS, c->rs);
             const PreOut po = { c->proj, c->rects, c->bin.ranges, (uint32_t)c->bin.zero_words() };
-            if (a.quads) HIPCHK(c, launch_preprocess_3d(c->st2, (const float*)data->d, npre, a.u, c->W, c->H, po));
-            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->st2, (const float*)data->d, npre, a.u, c->W, c->H, po));
-            else HIPCHK(c, launch_preprocess_4d(c->st2, data->soa, npre, a.u, c->W, c->H, po));
+            if (a.quads) HIPCHK(c, launch_preprocess_3d(c->rs, (const float*)data->d, npre, a.u, c->W, c->H, po));
+            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->rs, (const float*)data->d, npre, a.u, c->W, c->H, po));
+            else HIPCHK(c, launch_preprocess_4d(c->rs, data->soa, npre, a.u, c->W, c->H, po));
         }
-        HIPCHK(c, hipEventRecord(c->ev_pre_done, c->st2));
-        HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_pre_done, 0));
         c->proj_n = npre;
+        // binning reads the sort index (and any buffer the caller filled on `st` before this call)
+        HIPCHK(c, hipEventRecord(c->ev_order_ready, c->st));
+        HIPCHK(c, hipStreamWaitEvent(c->rs, c->ev_order_ready, 0));
     }
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
     if (c->pair_cap < want) { int rc = ensure_pairs(c, want); if (rc) return rc; }
-    return enqueue_raster(c, order, a.instances, npre, premult, a.fb_was_clear, preprocess);
+    return enqueue_raster(c, order, order_copy, a.instances, npre, premult, a.fb_was_clear, preprocess);
 }
 
 // A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
@@ -213,7 +236,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
 // re-run with exact capacity (the projected records are still valid; inputs are unchanged by construction).
 int resolve_pending(gs4d_ctx* c) {
     while (c->pending) {
-        HIPCHK(c, hipEventSynchronize(c->pending_ev));
+        HIPCHK(c, hipEventSynchronize(c->ev_emit_done));     // the entry count is final once the binning kernel has run
         c->pending = false;
         if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "radix sort: a look-back spin timed out on the device (results of this frame are invalid)");
         const uint64_t total = (uint64_t)c->host_total[2] | ((uint64_t)c->host_total[3] << 32);
@@ -232,14 +255,21 @@ int resolve_pending(gs4d_ctx* c) {
 
 int touches_pending(gs4d_ctx* c, gs4d_buf b) { return c->pending && (c->pending_args.data == b || c->pending_args.order == b); }
 
+// The order stage is about to overwrite `b`: if the in-flight draw reads its sort index from it, wait (on the device) until the
+// binning kernel has consumed and copied it.  No host synchronisation.
+int order_write_hazard(gs4d_ctx* c, gs4d_buf b) {
+    if (b != 0 && b == c->last_order) HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_emit_done, 0));
+    return GS4D_OK;
+}
+
 int materialise_fb(gs4d_ctx* c) {
-    if (c->fb_is_clear) { HIPCHK(c, launch_fill(c->st, c->fb, (size_t)c->W * c->H, c->clear)); c->fb_is_clear = false; }
+    if (c->fb_is_clear) { HIPCHK(c, launch_fill(c->rs, c->fb, (size_t)c->W * c->H, c->clear)); c->fb_is_clear = false; }
     return GS4D_OK;
 }
 
 int alloc_fb(gs4d_ctx* c, int w, int h) {
     if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return fail(c, GS4D_E_INVALID, "framebuffer size must be 1..65535");
-    if (c->fb) { HIPCHK(c, hipStreamSynchronize(c->st)); (void)hipFree(c->fb); c->fb = nullptr; }
+    if (c->fb) { int rc = sync_all(c); if (rc) return rc; (void)hipFree(c->fb); c->fb = nullptr; }
     HIPCHK(c, hipMalloc(&c->fb, (size_t)w * h * 16));
     c->W = w; c->H = h; c->tiles_x = (w + TILE - 1) / TILE; c->tiles_y = (h + TILE - 1) / TILE;
     c->fb_is_clear = true;
@@ -271,9 +301,8 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
     if ((e = hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
     c->st = c->own_st;
-    if ((e = hipEventCreateWithFlags(&c->pending_ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
-    if ((e = hipStreamCreateWithFlags(&c->st2, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
-    for (hipEvent_t* ev : { &c->ev_draw_done, &c->ev_soa, &c->ev_pre_done }) {
+    if ((e = hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
+    for (hipEvent_t* ev : { &c->ev_soa, &c->ev_order_ready, &c->ev_emit_done, &c->ev_readback }) {
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
         if ((e = hipEventRecord(*ev, c->st)) != hipSuccess) return bail(hipfail(c, e, "hipEventRecord"));      // "already happened"
     }
@@ -292,7 +321,8 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
-    if (c->st2) (void)hipStreamSynchronize(c->st2);
+    if (c->rs) (void)hipStreamSynchronize(c->rs);
+    if (c->order_copy) (void)hipFree(c->order_copy);
     for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); }
     if (c->fb) (void)hipFree(c->fb);
     if (c->proj) (void)hipFree(c->proj);
@@ -301,11 +331,10 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (c->pair_vals) (void)hipFree(c->pair_vals);
     sort_scratch_free(c->depth_sort); sort_scratch_free(c->pair_sort); bin_scratch_free(c->bin);
     if (c->host_total) (void)hipHostFree(c->host_total);
-    if (c->pending_ev) (void)hipEventDestroy(c->pending_ev);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t ev : { c->ev_draw_done, c->ev_soa, c->ev_pre_done }) if (ev) (void)hipEventDestroy(ev);
-    if (c->st2) (void)hipStreamDestroy(c->st2);
+    for (hipEvent_t ev : { c->ev_soa, c->ev_order_ready, c->ev_emit_done, c->ev_readback }) if (ev) (void)hipEventDestroy(ev);
+    if (c->rs) (void)hipStreamDestroy(c->rs);
     if (c->own_st) (void)hipStreamDestroy(c->own_st);
     delete c;
 }
@@ -344,7 +373,7 @@ int gs4d_buffer_subdata(gs4d_ctx* c, gs4d_buf b, size_t offset, const void* data
     if (offset > B->bytes || bytes > B->bytes - offset) return fail(c, GS4D_E_INVALID, "buffer_subdata: range outside the buffer");   // GL_INVALID_VALUE
     if (!bytes) return GS4D_OK;
     if (!data) return fail(c, GS4D_E_INVALID, "buffer_subdata: data == NULL");
-    if (touches_pending(c, b)) { int rc = resolve_pending(c); if (rc) return rc; }
+    if (touches_pending(c, b) || b == c->last_order) { int rc = resolve_pending(c); if (rc) return rc; rc = sync_all(c); if (rc) return rc; }
     // the caller keeps ownership of `data` and may reuse it on return (glBufferSubData semantics): copy synchronously
     HIPCHK(c, hipMemcpyAsync((char*)B->d + offset, data, bytes, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -369,12 +398,13 @@ int gs4d_buffer_destroy(gs4d_ctx* c, gs4d_buf b) {
     (void)hipSetDevice(c->device);
     Buffer* B = getbuf(c, b);
     if (!B) return GS4D_OK;                         // 0, unknown or already deleted: silently ignored, like glDeleteBuffers
-    if (touches_pending(c, b)) { int rc = resolve_pending(c); if (rc) return rc; }
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    { int rc = resolve_pending(c); if (rc) return rc; rc = sync_all(c); if (rc) return rc; }
     if (B->d) (void)hipFree(B->d);
     if (B->soa) (void)hipFree(B->soa);
     *B = Buffer();
     for (auto& s : c->slots) if (s == b) s = 0;     // a deleted buffer is unbound
+    if (c->last_order == b) c->last_order = 0;
+    if (c->kg_buf == b) c->kg_buf = 0;
     return GS4D_OK;
 }
 
@@ -440,7 +470,7 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     if (!K || !V) return fail(c, GS4D_E_INVALID, "sort_pairs: bad buffer name");
     if (K == V) return fail(c, GS4D_E_INVALID, "sort_pairs: keys and values must be different buffers");
     if (n >= 0xFFFFFFFFull || K->bytes < n * 4 || V->bytes < n * 4) return fail(c, GS4D_E_INVALID, "sort_pairs: buffers smaller than n elements");
-    if (touches_pending(c, keys) || touches_pending(c, vals)) { int rc = resolve_pending(c); if (rc) return rc; }
+    { int rc = order_write_hazard(c, keys); if (rc) return rc; rc = order_write_hazard(c, vals); if (rc) return rc; }
     // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
     const bool have_hist = c->depth_sort.hist_pending && keys == c->kg_buf && K->version == c->kg_ver && n == c->kg_n;
     StageTimer t(c, GS4D_T_SORT);
@@ -457,7 +487,7 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     if (key_mode != GS4D_KEY_REF_INV_EUCLID && key_mode != GS4D_KEY_VIEW_Z) return fail(c, GS4D_E_INVALID, "keygen: unknown key mode");
     if (n >= 0xFFFFFFFFull || D->bytes < n * 96 || K->bytes < n * 4 || I->bytes < n * 4) return fail(c, GS4D_E_INVALID, "keygen: buffers smaller than n elements");
     if (n == 0) return GS4D_OK;
-    if (touches_pending(c, keys) || touches_pending(c, idx)) { int rc = resolve_pending(c); if (rc) return rc; }
+    { int rc = order_write_hazard(c, keys); if (rc) return rc; rc = order_write_hazard(c, idx); if (rc) return rc; }
     int rc = ensure_soa(c, *D); if (rc) return rc;
     hipError_t he = hipSuccess;
     uint32_t* kh = sort_hist_slot(c->st, c->depth_sort, n, &he);
@@ -480,7 +510,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     c->proj_n = 0;
     rc = run_draw(c, a, true);
     if (rc) { c->proj_n = before; return rc; }
-    if (c->proj_n) { c->pending = true; c->pending_args = a; c->fb_is_clear = false; }   // proj_n != 0 <=> raster work was enqueued
+    if (c->proj_n) { c->pending = true; c->pending_args = a; c->fb_is_clear = false; c->last_order = a.order; }   // proj_n != 0 <=> raster work was enqueued
     if (c->profiling && c->prof_frame < gs4d_ctx::PROF_FRAMES) c->prof_frame++;
     return GS4D_OK;
 }
@@ -506,8 +536,8 @@ int gs4d_finish(gs4d_ctx* c) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "radix sort: a look-back spin timed out on the device");
+    rc = sync_all(c); if (rc) return rc;
+    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "a bounded device-side wait timed out (radix sort / binning look-back): results are invalid");
     return GS4D_OK;
 }
 
@@ -517,8 +547,9 @@ int gs4d_read_pixels(gs4d_ctx* c, float* rgba, size_t bytes) {
     if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels: bytes != width*height*16");
     int rc = resolve_pending(c); if (rc) return rc;
     rc = materialise_fb(c); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(rgba, c->fb, bytes, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemcpyAsync(rgba, c->fb, bytes, hipMemcpyDeviceToHost, c->rs));
+    HIPCHK(c, hipStreamSynchronize(c->rs));
+    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "a bounded device-side wait timed out (radix sort / binning look-back): results are invalid");
     return GS4D_OK;
 }
 
@@ -528,7 +559,9 @@ int gs4d_read_pixels_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels_device: bytes != width*height*16");
     int rc = resolve_pending(c); if (rc) return rc;
     rc = materialise_fb(c); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(dptr, c->fb, bytes, hipMemcpyDeviceToDevice, c->st));
+    HIPCHK(c, hipMemcpyAsync(dptr, c->fb, bytes, hipMemcpyDeviceToDevice, c->rs));
+    HIPCHK(c, hipEventRecord(c->ev_readback, c->rs));
+    HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_readback, 0));      // work the caller queues on `st` after this call sees the pixels
     return GS4D_OK;
 }
 
@@ -538,7 +571,9 @@ int gs4d_read_pixels_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_pixels_rgba8_device: bytes != width*height*4");
     int rc = resolve_pending(c); if (rc) return rc;
     rc = materialise_fb(c); if (rc) return rc;
-    HIPCHK(c, launch_pack_rgba8(c->st, c->fb, (size_t)c->W * c->H, (uint32_t*)dptr));
+    HIPCHK(c, launch_pack_rgba8(c->rs, c->fb, (size_t)c->W * c->H, (uint32_t*)dptr));
+    HIPCHK(c, hipEventRecord(c->ev_readback, c->rs));
+    HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_readback, 0));      // work the caller queues on `st` after this call sees the pixels
     return GS4D_OK;
 }
 
@@ -546,7 +581,7 @@ int gs4d_set_stream(gs4d_ctx* c, void* hip_stream) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->st));          // everything queued so far completes before work moves to the other stream
+    rc = sync_all(c); if (rc) return rc;             // everything queued so far completes before work moves to the other stream
     c->st = hip_stream ? (hipStream_t)hip_stream : c->own_st;
     return GS4D_OK;
 }
@@ -570,7 +605,7 @@ int gs4d_get_timings(gs4d_ctx* c, float ms[GS4D_T_COUNT]) {
     if (!c || !ms) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    rc = sync_all(c); if (rc) return rc;
     // average per stage over the frames recorded since profiling was switched on (or since the last call); then restart
     for (int i = 0; i < GS4D_T_COUNT; ++i) {
         double sum = 0; int cnt = 0;
@@ -600,8 +635,8 @@ int gs4d_debug_read_projected(gs4d_ctx* c, float* out16, size_t nrecords) {
     (void)hipSetDevice(c->device);
     if (nrecords > c->proj_n) return fail(c, GS4D_E_INVALID, "debug_read_projected: more records than the last draw projected");
     int rc = resolve_pending(c); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out16, c->proj, nrecords * 64, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemcpyAsync(out16, c->proj, nrecords * 64, hipMemcpyDeviceToHost, c->rs));
+    HIPCHK(c, hipStreamSynchronize(c->rs));
     // expose the layout documented in gs4d.h: cx,cy,a0x,a0y,a1x,a1y,alpha,r,g,b,rect0,rect1,hx,hy,valid,0  (already the storage order)
     return GS4D_OK;
 }
