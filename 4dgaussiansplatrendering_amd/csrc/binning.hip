@@ -55,9 +55,12 @@ __device__ __forceinline__ void emit_tiles(const Rect& r, uint32_t off, uint32_t
     }
 }
 
-// status[b] is one 64-bit {flag:2,value:62} granule per workgroup, written/polled with agent-scope relaxed atomics (same
-// hand-off form as the radix sort's look-back words); it is zeroed by the preprocess kernel of the same draw.
-constexpr unsigned long long BS_AGG = 1ull << 62, BS_INCL = 2ull << 62, BS_VAL = (1ull << 62) - 1ull;
+// status[b] is one 64-bit {epoch:22, flag:2, value:40} granule per workgroup, written/polled with agent-scope relaxed atomics (same
+// hand-off form as the radix sort's look-back words).  The epoch (one per launch) makes the words of earlier draws read as "not
+// published", so they are never zeroed.
+constexpr unsigned long long BS_VAL = (1ull << 40) - 1ull;
+__device__ __forceinline__ unsigned long long bs_word(uint32_t epoch, unsigned long long flag, unsigned long long v) { return ((unsigned long long)epoch << 42) | (flag << 40) | (v > BS_VAL ? BS_VAL : v); }
+__device__ __forceinline__ uint32_t bs_flag(unsigned long long w, uint32_t epoch) { return (uint32_t)(w >> 42) == epoch ? (uint32_t)(w >> 40) & 3u : 0u; }
 
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
@@ -68,7 +71,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
                                                           unsigned long long* status, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
                                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
-                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host) {
+                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch) {
     __shared__ uint32_t wsum[4];
     __shared__ unsigned long long s_prefix;
     __shared__ uint32_t h[OS_MAX_PASSES][256];
@@ -99,15 +102,15 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
     // publish this workgroup's total, look back for the exclusive prefix (wave 0, 64 predecessors per step)
     if (tid < 64) {
         unsigned long long prefix = 0;
-        if (blk == 0) { if (lane == 0) __hip_atomic_store(status, BS_INCL | (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        if (blk == 0) { if (lane == 0) __hip_atomic_store(status, bs_word(epoch, 2ull, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         else {
-            if (lane == 0) __hip_atomic_store(status + blk, BS_AGG | (unsigned long long)run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(status + blk, bs_word(epoch, 1ull, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int64_t p = (int64_t)blk - 1;
             uint32_t spins = 0;
             while (true) {
                 const int64_t idx = p - (int64_t)lane;
-                const unsigned long long v = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : BS_INCL;   // before workgroup 0: inclusive 0
-                const uint32_t f = (uint32_t)(v >> 62);
+                const unsigned long long v = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bs_word(epoch, 2ull, 0ull);   // before workgroup 0: inclusive 0
+                const uint32_t f = bs_flag(v, epoch);
                 const uint64_t none = __ballot(f == 0u), incl = __ballot(f == 2u);
                 const uint64_t low = incl & (0ull - incl);                                     // nearest INCL
                 const uint64_t upto = incl ? (low | (low - 1ull)) : ~0ull;                       // lanes up to and including it
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
                 if (incl) break;
                 p -= 64;
             }
-            if (lane == 0) __hip_atomic_store(status + blk, BS_INCL | ((prefix + run) & BS_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(status + blk, bs_word(epoch, 2ull, prefix + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) {
             s_prefix = prefix;
@@ -186,8 +189,9 @@ hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size
         if (b.ranges) { (void)hipStreamSynchronize(st); (void)hipFree(b.ranges); }
         const size_t nb2 = nb > b.block_cap ? nb : b.block_cap, nt2 = ntiles > b.tiles_cap ? ntiles : b.tiles_cap;
         b.ranges = nullptr; b.status = nullptr; b.block_cap = b.tiles_cap = 0;
-        // one allocation, zeroed as a whole each draw: [ranges: 2*tiles u32][status: blocks u64]
+        // one allocation: [ranges: 2*tiles u32][status: blocks u64]
         if ((e = hipMalloc(&b.ranges, nt2 * 8 + nb2 * 8)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(b.ranges, 0, nt2 * 8 + nb2 * 8, st)) != hipSuccess) return e;    // ranges stay zero between draws: the composite clears what it reads
         b.status = reinterpret_cast<unsigned long long*>(b.ranges + 2 * nt2);
         b.block_cap = nb2; b.tiles_cap = nt2;
     }
@@ -203,8 +207,13 @@ void bin_scratch_free(BinScratch& b) {
 hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
                           uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host) {
     (void)tiles_y;
+    if (++b.epoch >= (1u << 22)) {            // epoch wrap: forget every old word
+        hipError_t e = hipMemsetAsync(b.status, 0, b.block_cap * 8, st);
+        if (e != hipSuccess) return e;
+        b.epoch = 1;
+    }
     const uint32_t nb = (uint32_t)((ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host);
+    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch);
     return hipGetLastError();
 }
 

@@ -67,7 +67,7 @@ __device__ __forceinline__ void blend_fragment(float u, float v, float alpha, fl
 }
 
 template <bool PREMULT_C>
-__global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ proj, const uint32_t* __restrict__ pair_vals, const uint32_t* __restrict__ ranges,
+__global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ proj, const uint32_t* __restrict__ pair_vals, uint32_t* __restrict__ ranges,
                                                   const uint32_t* __restrict__ total, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
                                                   float4* __restrict__ fb, int dbg) {
     __shared__ float4 stage[64 * 3];
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
     const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    if (lane < 2u && end != 0u) ranges[2 * tile + lane] = 0u;      // leave the table all-zero for the next draw (no memset launch)
 
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
     for (uint32_t hi = end; hi > start;) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
     }
 }
 
-hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, const uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
+hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
                             int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb) {
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid((unsigned)(tiles_x * tiles_y));

@@ -36,6 +36,7 @@ struct DrawArgs {
     size_t instances = 0;
     bool quads = false;
     bool fb_was_clear = false;     // framebuffer state the composite of this draw must start from (kept for a re-run)
+    int pre_idx = 0;               // which projected-record buffer the draw uses
 };
 
 thread_local std::string g_create_error;
@@ -52,6 +53,9 @@ struct gs4d_ctx {
     // order stage of frame f+1 touch disjoint data (the draw keeps a private copy of the sort index it was given), so consecutive
     // frames overlap on the GPU; the events below carry the few true dependencies.
     hipStream_t rs = nullptr;
+    hipStream_t ps = nullptr;             // preprocess stream: the projection of frame f+1 runs beside both stages (double-buffered outputs)
+    hipEvent_t ev_pre_done = nullptr;     // ps: projected records written                  -> rs waits before binning
+    hipEvent_t ev_raster_done[2] = { nullptr, nullptr };   // rs: the composite that read proj[i] has finished -> ps waits before overwriting proj[i]
     hipEvent_t ev_soa = nullptr;          // st: SoA shadow rebuilt                          -> rs waits before preprocess
     hipEvent_t ev_order_ready = nullptr;  // st: everything queued before the draw call      -> rs waits before binning reads the sort index
     hipEvent_t ev_emit_done = nullptr;    // rs: binning has read (and copied) the sort index -> st waits before overwriting that buffer
@@ -67,8 +71,9 @@ struct gs4d_ctx {
     float4* fb = nullptr;
     bool fb_is_clear = true;           // framebuffer content == clear colour, not yet materialised
     // per-draw scratch
-    float4* proj = nullptr; size_t proj_cap = 0; size_t proj_n = 0;
-    uint2* rects = nullptr;            // compact pixel rectangles, one per projected record
+    float4* proj2[2] = { nullptr, nullptr }; size_t proj_cap = 0; size_t proj_n = 0;   // projected records, double-buffered across draws
+    uint2* rects2[2] = { nullptr, nullptr };   // compact pixel rectangles, one per projected record
+    int pre_idx = 0;                   // buffer the latest draw projected into
     uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;
     SortScratch depth_sort, pair_sort;
     BinScratch bin;
@@ -110,6 +115,7 @@ struct StageTimer {
 
 int sync_all(gs4d_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipStreamSynchronize(c->ps));
     HIPCHK(c, hipStreamSynchronize(c->rs));
     return GS4D_OK;
 }
@@ -141,17 +147,16 @@ int ensure_pairs(gs4d_ctx* c, size_t cap) {
 }
 
 // Enqueue binning -> tile sort -> ranges -> composite on the raster stream for projected records already in c->proj.
-int enqueue_raster(gs4d_ctx* c, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, bool zeroed) {
+int enqueue_raster(gs4d_ctx* c, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, int pre_idx) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
     {
         StageTimer t(c, GS4D_T_BINNING, c->rs);
-        if (!zeroed) HIPCHK(c, hipMemsetAsync(c->bin.ranges, 0, c->bin.zero_words() * 4, c->rs));      // re-run of a draw: preprocess did not run
         hipError_t he = hipSuccess;
         uint32_t* ph = sort_hist_slot(c->rs, c->pair_sort, c->pair_cap, &he);      // the emit kernel also counts the tile-id digits
         if (!ph) return hipfail(c, he, "sort_hist_slot");
-        HIPCHK(c, launch_binning(c->rs, c->bin, c->rects, order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err,
+        HIPCHK(c, launch_binning(c->rs, c->bin, c->rects2[pre_idx], order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err,
                                  ph, tile_passes, c->host_total_dev));
     }
     HIPCHK(c, hipEventRecord(c->ev_emit_done, c->rs));     // the last binning workgroup wrote the total straight into pinned host memory
@@ -162,8 +167,9 @@ int enqueue_raster(gs4d_ctx* c, const uint32_t* order, uint32_t* order_copy, siz
     }
     {
         StageTimer t(c, GS4D_T_COMPOSITE, c->rs);
-        HIPCHK(c, launch_composite(c->rs, c->proj, c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
+        HIPCHK(c, launch_composite(c->rs, c->proj2[pre_idx], c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
     }
+    HIPCHK(c, hipEventRecord(c->ev_raster_done[pre_idx], c->rs));
     return GS4D_OK;
 }
 
@@ -202,24 +208,25 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (preprocess) {
         if (c->proj_cap < npre) {
             int rc = sync_all(c); if (rc) return rc;
-            if (c->proj) (void)hipFree(c->proj);
-            if (c->rects) (void)hipFree(c->rects);
-            c->proj = nullptr; c->rects = nullptr; c->proj_cap = 0;
-            HIPCHK(c, hipMalloc(&c->proj, npre * 64));
-            HIPCHK(c, hipMalloc(&c->rects, npre * 8));
+            for (int i = 0; i < 2; ++i) { if (c->proj2[i]) (void)hipFree(c->proj2[i]); if (c->rects2[i]) (void)hipFree(c->rects2[i]); c->proj2[i] = nullptr; c->rects2[i] = nullptr; }
+            c->proj_cap = 0;
+            for (int i = 0; i < 2; ++i) { HIPCHK(c, hipMalloc(&c->proj2[i], npre * 64)); HIPCHK(c, hipMalloc(&c->rects2[i], npre * 8)); }
             c->proj_cap = npre;
         }
         if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
-        // The projection does not depend on the sort: on the raster stream it runs beside the key generation / depth sort that the
-        // caller queued on `st` for this frame (and follows the previous frame's composite, whose records it overwrites).
-        HIPCHK(c, hipStreamWaitEvent(c->rs, c->ev_soa, 0));
+        // The projection depends on neither the sort nor the previous frame's raster stage: it has a stream of its own and two
+        // output buffers, so it runs beside the key generation / depth sort of this frame and the compositing of the last one.
+        HIPCHK(c, hipStreamWaitEvent(c->ps, c->ev_soa, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->ps, c->ev_raster_done[a.pre_idx], 0));      // the draw two back, which read this buffer
         {
-            StageTimer t(c, GS4D_T_PREPROCESS, c->rs);
-            const PreOut po = { c->proj, c->rects, c->bin.ranges, (uint32_t)c->bin.zero_words() };
-            if (a.quads) HIPCHK(c, launch_preprocess_3d(c->rs, (const float*)data->d, npre, a.u, c->W, c->H, po));
-            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->rs, (const float*)data->d, npre, a.u, c->W, c->H, po));
-            else HIPCHK(c, launch_preprocess_4d(c->rs, data->soa, npre, a.u, c->W, c->H, po));
+            StageTimer t(c, GS4D_T_PREPROCESS, c->ps);
+            const PreOut po = { c->proj2[a.pre_idx], c->rects2[a.pre_idx] };
+            if (a.quads) HIPCHK(c, launch_preprocess_3d(c->ps, (const float*)data->d, npre, a.u, c->W, c->H, po));
+            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->ps, (const float*)data->d, npre, a.u, c->W, c->H, po));
+            else HIPCHK(c, launch_preprocess_4d(c->ps, data->soa, npre, a.u, c->W, c->H, po));
         }
+        HIPCHK(c, hipEventRecord(c->ev_pre_done, c->ps));
+        HIPCHK(c, hipStreamWaitEvent(c->rs, c->ev_pre_done, 0));
         c->proj_n = npre;
         // binning reads the sort index (and any buffer the caller filled on `st` before this call)
         HIPCHK(c, hipEventRecord(c->ev_order_ready, c->st));
@@ -228,7 +235,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
     if (c->pair_cap < want) { int rc = ensure_pairs(c, want); if (rc) return rc; }
-    return enqueue_raster(c, order, order_copy, a.instances, npre, premult, a.fb_was_clear, preprocess);
+    return enqueue_raster(c, order, order_copy, a.instances, npre, premult, a.fb_was_clear, a.pre_idx);
 }
 
 // A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
@@ -302,7 +309,8 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
     c->st = c->own_st;
     if ((e = hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
-    for (hipEvent_t* ev : { &c->ev_soa, &c->ev_order_ready, &c->ev_emit_done, &c->ev_readback }) {
+    if ((e = hipStreamCreateWithFlags(&c->ps, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
+    for (hipEvent_t* ev : { &c->ev_soa, &c->ev_order_ready, &c->ev_emit_done, &c->ev_readback, &c->ev_pre_done, &c->ev_raster_done[0], &c->ev_raster_done[1] }) {
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
         if ((e = hipEventRecord(*ev, c->st)) != hipSuccess) return bail(hipfail(c, e, "hipEventRecord"));      // "already happened"
     }
@@ -322,19 +330,20 @@ void gs4d_destroy(gs4d_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->st) (void)hipStreamSynchronize(c->st);
     if (c->rs) (void)hipStreamSynchronize(c->rs);
+    if (c->ps) (void)hipStreamSynchronize(c->ps);
     if (c->order_copy) (void)hipFree(c->order_copy);
     for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); }
     if (c->fb) (void)hipFree(c->fb);
-    if (c->proj) (void)hipFree(c->proj);
-    if (c->rects) (void)hipFree(c->rects);
+    for (int i = 0; i < 2; ++i) { if (c->proj2[i]) (void)hipFree(c->proj2[i]); if (c->rects2[i]) (void)hipFree(c->rects2[i]); }
     if (c->pair_keys) (void)hipFree(c->pair_keys);
     if (c->pair_vals) (void)hipFree(c->pair_vals);
     sort_scratch_free(c->depth_sort); sort_scratch_free(c->pair_sort); bin_scratch_free(c->bin);
     if (c->host_total) (void)hipHostFree(c->host_total);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t ev : { c->ev_soa, c->ev_order_ready, c->ev_emit_done, c->ev_readback }) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : { c->ev_soa, c->ev_order_ready, c->ev_emit_done, c->ev_readback, c->ev_pre_done, c->ev_raster_done[0], c->ev_raster_done[1] }) if (ev) (void)hipEventDestroy(ev);
     if (c->rs) (void)hipStreamDestroy(c->rs);
+    if (c->ps) (void)hipStreamDestroy(c->ps);
     if (c->own_st) (void)hipStreamDestroy(c->own_st);
     delete c;
 }
@@ -506,11 +515,12 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     Buffer* d = getbuf(c, a.data); Buffer* o = getbuf(c, a.order);
     a.data_version = d ? d->version : 0; a.order_version = o ? o->version : 0;
     a.fb_was_clear = c->fb_is_clear;
+    a.pre_idx = c->pre_idx ^ 1;
     const size_t before = c->proj_n;
     c->proj_n = 0;
     rc = run_draw(c, a, true);
     if (rc) { c->proj_n = before; return rc; }
-    if (c->proj_n) { c->pending = true; c->pending_args = a; c->fb_is_clear = false; c->last_order = a.order; }   // proj_n != 0 <=> raster work was enqueued
+    if (c->proj_n) { c->pending = true; c->pending_args = a; c->fb_is_clear = false; c->last_order = a.order; c->pre_idx = a.pre_idx; }   // proj_n != 0 <=> raster work was enqueued
     if (c->profiling && c->prof_frame < gs4d_ctx::PROF_FRAMES) c->prof_frame++;
     return GS4D_OK;
 }
@@ -635,7 +645,7 @@ int gs4d_debug_read_projected(gs4d_ctx* c, float* out16, size_t nrecords) {
     (void)hipSetDevice(c->device);
     if (nrecords > c->proj_n) return fail(c, GS4D_E_INVALID, "debug_read_projected: more records than the last draw projected");
     int rc = resolve_pending(c); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out16, c->proj, nrecords * 64, hipMemcpyDeviceToHost, c->rs));
+    HIPCHK(c, hipMemcpyAsync(out16, c->proj2[c->pre_idx], nrecords * 64, hipMemcpyDeviceToHost, c->rs));
     HIPCHK(c, hipStreamSynchronize(c->rs));
     // expose the layout documented in gs4d.h: cx,cy,a0x,a0y,a1x,a1y,alpha,r,g,b,rect0,rect1,hx,hy,valid,0  (already the storage order)
     return GS4D_OK;

@@ -85,9 +85,8 @@ __device__ __forceinline__ void os_hist_flush(uint32_t (*h)[256], uint32_t* __re
 
 // ---- preprocess.hip ----
 hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* 6 planes of n float4 */);
-// Each preprocess launch also writes the compact pixel rectangle of every record and zeroes `zero_words` words at `zero` (the
-// binning control block of the same draw), so the draw needs no memset launch.
-struct PreOut { float4* proj; uint2* rects; uint32_t* zero; uint32_t zero_words; };
+// Each preprocess launch also writes the compact pixel rectangle of every record.
+struct PreOut { float4* proj; uint2* rects; };
 hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& u, int W, int H, PreOut out);
 hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, PreOut out);
 hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, PreOut out);
@@ -96,9 +95,9 @@ hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, co
 struct BinScratch {
     uint32_t* total = nullptr;        // [0] = number of tile-list entries (saturated), [1] = overflow flag, [2..3] = 64-bit count
     uint32_t* ranges = nullptr; size_t tiles_cap = 0;           // [2*tiles] start,end — followed in the same allocation by
-    unsigned long long* status = nullptr; size_t block_cap = 0; // the chained-scan words of the binning workgroups
-    // ranges+status are zeroed together at the start of every draw (by the preprocess kernel, or a memset when a draw is re-run)
-    size_t zero_words() const { return 2 * tiles_cap + 2 * block_cap; }
+    unsigned long long* status = nullptr; size_t block_cap = 0; // the chained-scan words of the binning workgroups (epoch-tagged, never zeroed)
+    uint32_t epoch = 0;
+    // ranges are all-zero between draws: k_tile_ranges fills the non-empty tiles, the composite kernel clears each range it has read
 };
 hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size_t ntiles);
 void bin_scratch_free(BinScratch& b);
@@ -108,7 +107,7 @@ hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, con
 hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pair_keys, size_t pair_cap, size_t ntiles);
 
 // ---- composite.hip ----
-hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, const uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
+hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
                             int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb);
 hipError_t launch_fill(hipStream_t st, float4* fb, size_t npix, const float clear[4]);
 hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, size_t npix, uint32_t* out);

@@ -154,7 +154,6 @@ __device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float
 
 __global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict__ soa, uint32_t n, PU u, PreOut out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    for (uint32_t z = i; z < out.zero_words; z += gridDim.x * 256u) out.zero[z] = 0u;
     if (i >= n) return;
     const float4 pos = soa[i], col = soa[(size_t)n + i];
     const float4 s0 = soa[(size_t)2 * n + i], s1 = soa[(size_t)3 * n + i], s2 = soa[(size_t)4 * n + i], s3 = soa[(size_t)5 * n + i];
@@ -180,7 +179,6 @@ __global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict_
 
 __global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__ verts, uint32_t n, PU u, PreOut out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    for (uint32_t z = i; z < out.zero_words; z += gridDim.x * 256u) out.zero[z] = 0u;
     if (i >= n) return;
     const float* v = verts + (size_t)72 * i;      // vertex 0 of the quad: {vpos2, spos3, col4, sig9}
     float C[3][3];
@@ -195,7 +193,6 @@ __global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__
 
 __global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__ recs, uint32_t n, PU u, PreOut out) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    for (uint32_t z = i; z < out.zero_words; z += gridDim.x * 256u) out.zero[z] = 0u;
     if (i >= n) return;
     const float* rec = recs + (size_t)12 * i;
     const float* P = u.P;

@@ -81,10 +81,11 @@ def main():
     stream = torch.cuda.current_stream()
     ctx.set_stream(stream.cuda_stream)          # HIP stream shared with torch so that the gather orders after the draw
     data = ctx.buffer(rec)
-    keys, idx = ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    # per-frame key / sort-index buffers are double-buffered by the application (as any renderer does with per-frame resources):
+    # frame f+1 can generate and sort its keys while frame f's binning still reads frame f's sort index
+    keybufs = [(ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)) for _ in range(2)]
     ctx.set_clear_color(gs4d.CLEAR_COLOR)
     ctx.set_mode(gs4d.MODE_4D_SORTED)
-    ctx.bind(1, idx)
     ctx.bind(2, data)
     ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
 
@@ -99,10 +100,12 @@ def main():
     def step(k):
         # frame of this rank in the time sweep (frame f -> rank f mod world); static 3D records ignore t
         t = sharding.sweep_time(sharding.frame_of(k, rank, world), total_frames) if multi else 0.0
+        keys, idx = keybufs[k & 1]
         ctx.clear()
         ctx.set_uniforms(time=t)
         ctx.keygen(data, t, cam[0], keys, idx, n)
         ctx.sort_pairs(keys, idx, n)
+        ctx.bind(1, idx)
         ctx.draw_instanced(n)
         if multi:
             ctx.read_pixels_rgba8_device(frame8.data_ptr(), frame8.numel() * 4)
