@@ -71,12 +71,17 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
                                                           unsigned long long* status, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
                                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
-                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch) {
+                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base) {
     __shared__ uint32_t wsum[4];
     __shared__ unsigned long long s_prefix;
+    __shared__ uint32_t s_blk;
     __shared__ uint32_t h[OS_MAX_PASSES][256];
     os_hist_clear(h, threadIdx.x);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, blk = blockIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // the slice of instances is handed out by ticket (start order), so the look-back only ever waits for running workgroups
+    if (tid == 0) s_blk = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t blk = s_blk;
     const uint32_t base = blk * (BIN_THREADS * BIN_ITEMS);
     Rect r[BIN_ITEMS]; uint32_t rec[BIN_ITEMS], off[BIN_ITEMS];
     uint32_t run = 0;
@@ -182,8 +187,9 @@ hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size
     size_t nb = (ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS);
     if (nb < 1) nb = 1;
     if (!b.total) {
-        if ((e = hipMalloc(&b.total, 16)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(b.total, 0, 16, st)) != hipSuccess) return e;
+        if ((e = hipMalloc(&b.total, 64)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(b.total, 0, 64, st)) != hipSuccess) return e;
+        b.ticket_base = 0;
     }
     if (b.block_cap < nb || b.tiles_cap < ntiles) {
         if (b.ranges) { (void)hipStreamSynchronize(st); (void)hipFree(b.ranges); }
@@ -213,7 +219,8 @@ hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, con
         b.epoch = 1;
     }
     const uint32_t nb = (uint32_t)((ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch);
+    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch, b.total + 8, b.ticket_base);
+    b.ticket_base += nb;
     return hipGetLastError();
 }
 

@@ -31,6 +31,7 @@ struct SortScratch {
     int flip = 0;
     bool hist_pending = false;         // the current slot holds a histogram accumulated by a producer kernel, not yet consumed by a sort
     uint32_t epoch = 0;                // tag of the look-back words of the latest pass launch
+    uint32_t ticket_base = 0;          // value of the ticket counter (totals[64]) at the start of the next pass launch
     uint32_t* totals = nullptr;                                             // [256] spare words (err word when `err` is not set)
     uint32_t* err = nullptr;                                                // not owned: device word raised when a look-back spin times out
 };
@@ -97,6 +98,7 @@ struct BinScratch {
     uint32_t* ranges = nullptr; size_t tiles_cap = 0;           // [2*tiles] start,end — followed in the same allocation by
     unsigned long long* status = nullptr; size_t block_cap = 0; // the chained-scan words of the binning workgroups (epoch-tagged, never zeroed)
     uint32_t epoch = 0;
+    uint32_t ticket_base = 0;         // total[8] is the ticket counter of the binning workgroups
     // ranges are all-zero between draws: k_tile_ranges fills the non-empty tiles, the composite kernel clears each range it has read
 };
 hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size_t ntiles);

@@ -85,9 +85,9 @@ hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, 
 // launch) makes words of earlier launches read as "not published", so the words are never zeroed.
 // Look-back is two-level (tiles in groups of OS_GROUP; the last tile of a group publishes the group's total): when all tiles of a
 // small sort start together, a tile needs ~3 memory round trips instead of one per ~32 predecessors.
-// Tile id = blockIdx.x: a tile waits only for lower-numbered tiles, which the dispatcher has started earlier (observed in-order
-// dispatch; not an API guarantee), so every spin is bounded: on time-out the kernel raises `err` and leaves, and the host reports
-// the frame as failed instead of hanging the GPU or returning wrong data.
+// Tile ids are tickets (an atomic counter, one per started workgroup): a tile waits only for tiles that are already running, whatever
+// the dispatch order.  Every spin is bounded as well: on time-out the kernel raises `err` and leaves, and the host reports the
+// frame as failed instead of hanging the GPU or returning wrong data.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t OS_GROUP = 32;         // tiles per look-back group
 typedef unsigned long long u64;
@@ -227,7 +227,7 @@ template <int THREADS, int ITEMS>
 __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
                                                      const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
                                                      uint32_t* status /* [tiles][256] */, u64* gstatus /* [groups][256] */, uint32_t epoch, uint32_t* err,
-                                                     u64* stamps /* tuning aid, may be null */) {
+                                                     uint32_t* ticket, uint32_t ticket_base, u64* stamps /* tuning aid, may be null */) {
     constexpr uint32_t TILE_KEYS = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
     static_assert(TILE_KEYS < (1u << 14), "tile-level look-back words carry 14-bit counts");
@@ -238,10 +238,16 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     __shared__ uint32_t gpos[256];      // global slot of that first element
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_live[OS_MAX_PASSES];
+    __shared__ uint32_t s_tile;
 
     const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t tile = blockIdx.x;
+    // Tile ids are handed out by ticket, in the order workgroups START: a tile only ever waits for tiles that are already running.
+    // (With blockIdx as the tile id, two chained-scan kernels running side by side on different streams can dead-lock each other:
+    // workgroups are dispatched per XCD, so each kernel's late tiles can fill the XCD the other kernel's early tiles need.)
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
     const uint32_t ntiles = (n + TILE_KEYS - 1u) / TILE_KEYS;
     if (pass == 0 && tile == 0) { for (uint32_t q = tid; q < OS_SLOT_WORDS; q += THREADS) ghist_other[q] = 0u; }   // the histogram slot of the NEXT sort
     if (tile >= ntiles) return;                                   // uniform
@@ -428,7 +434,8 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
             ++s.epoch;
         }
         k_os_pass<THREADS, ITEMS><<<dim3(tiles), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, gstatus, s.epoch & 0x3FFFFFFFu,
-                                                                         s.err ? s.err : s.totals, (stampf && p == stamp_pass) ? stamps : nullptr);
+                                                                         s.err ? s.err : s.totals, s.totals + 64, s.ticket_base, (stampf && p == stamp_pass) ? stamps : nullptr);
+        s.ticket_base += tiles;               // every workgroup of the launch draws exactly one ticket
     }
     if (stampf && stamps) {   // tuning aid: dump per-tile wall-clock stamps (100 MHz) of one pass
         (void)hipStreamSynchronize(st);

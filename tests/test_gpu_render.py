@@ -91,9 +91,9 @@ def test_teapot_first1000_reference_records(ctx1080, gs4d, oracle):
     assert stats["reruns"] == 0
 
 
-@pytest.mark.parametrize("n", [1, 777, 20000, 1000000])
+@pytest.mark.parametrize("n", [1, 777, 20000, 1000000, 10000000])
 def test_cube_1080p(ctx1080, gs4d, oracle, n):
-    """Config 2 (n = 1e6) and smaller cuts of it: random 3D splats in the 400^3 cube, screenshot camera, 1080p."""
+    """Configs 2 and 3 (n = 1e6, 1e7) and smaller cuts: random 3D splats in the 400^3 cube, screenshot camera, 1080p."""
     pos, q, scale, rgba = scenes.cube_params(n)
     rec = gs4d.build_records_3d(pos, q, scale, rgba)
     img, projd, stats, (view, proj) = gpu_frame(ctx1080, gs4d, rec, scenes.CAM_CUBE)
@@ -117,6 +117,34 @@ def test_time_sweep_4d(gs4d, oracle):
         check_projected(oracle, projd, oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, mo))
         assert linf(img, eimg) <= TOL
     ctx.close()
+
+
+def test_nonlinear_teapot_4k(gs4d, oracle):
+    """Config 5 in miniature: the NonLinearMotion scene (circular path, Scenes.h:517-545) at its reference size (335 248 splats)
+    on a 3840x2160 frame, camera (0,60,60) -> (0,-1,-1), mid-sweep.  4K has 129 600 tiles: three tile-sort passes, long lists."""
+    W, H = 3840, 2160
+    ctx = gs4d.Context(W, H)
+    rec = gs4d.scene_nonlinear(oracle.golden("teapot_vdata"))
+    t = 46.0
+    img, projd, stats, (view, proj) = gpu_frame(ctx, gs4d, rec, scenes.CAM_NONLINEAR, t=t)
+    eimg, _, _ = oracle.render_4d(rec, True, t, 0.0, scenes.CAM_NONLINEAR[0], view, proj, W, H, nthreads=16)
+    check_projected(oracle, projd, oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, 0.0))
+    assert linf(img, eimg) <= TOL
+    assert np.abs(eimg - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.3
+    assert stats["tiles"] == 480 * 270
+    ctx.close()
+
+
+def test_time_sweep_1e6_4d_splats(ctx1080, gs4d, oracle):
+    """Config 4, one frame of the sweep at full size: 1e6 4D splats (velocity, lifetime, mu_t in [0,50]) at t = 50*100/255."""
+    n = 1000000
+    pos4, q, scale, life, fade, vel, rgba = scenes.cube_params_4d(n)
+    rec = gs4d.build_records_4d(pos4, q, scale, life, fade, vel, rgba)
+    t = 50.0 * 100 / 255
+    img, projd, _, (view, proj) = gpu_frame(ctx1080, gs4d, rec, scenes.CAM_CUBE, t=t)
+    eimg, _, _ = oracle.render_4d(rec, True, t, 0.0, scenes.CAM_CUBE[0], view, proj, 1920, 1080, nthreads=16)
+    check_projected(oracle, projd, oracle.preprocess(oracle.MODE_4D, rec, view, proj, 1920, 1080, t, 0.0))
+    assert linf(img, eimg) <= TOL
 
 
 def test_unsorted_and_arbitrary_order(gs4d, oracle):

@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage: tools/profile_round.sh <tag> <splats> <steps>   (on the GPU box, from the repo root)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+tag=$1; n=$2; steps=$3; warm=5; frames=$((steps+warm))
+out=gpurun_out/$tag; mkdir -p $out
+python3 bench.py --splats $n --steps 200 --warmup 20 > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --splats $n --steps $steps --warmup $warm --no-cpu-baseline > $out/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py --splats $n --steps $steps --warmup $warm --no-cpu-baseline > $out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --splats $n --steps $steps --warmup $warm --no-cpu-baseline > $out/pmc_write.log 2>&1
+python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $frames $out/pmc_traffic.json > $out/pmc_traffic.txt 2>&1
+cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
+rm -rf $out/trace $out/pmc_fetch $out/pmc_write
+tail -c 600 $out/bench.json; echo; cat $out/pmc_traffic.txt
