@@ -60,11 +60,17 @@ def main():
     import scenes
     gs4d = importlib.import_module("4dgaussiansplatrendering_amd")     # raises if libgs4d.so is missing: no fallback
 
+    backend = os.environ.get("GS4D_BENCH_BACKEND", "nccl")      # "gloo" only to rehearse the N>1 code path on a one-GPU box
+    if backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if multi:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n = args.splats
     cam = scenes.CAM_CUBE
@@ -90,9 +96,10 @@ def main():
     ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
 
     frame8 = gathered = None
+    gdev = "cuda" if backend == "nccl" else "cpu"
     if multi:
         frame8 = torch.empty(H * W, dtype=torch.int32, device="cuda")
-        gathered = [torch.empty_like(frame8) for _ in range(world)] if rank == 0 else None
+        gathered = [torch.empty(H * W, dtype=torch.int32, device=gdev) for _ in range(world)] if rank == 0 else None
 
     sharding = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
     total_frames = (args.warmup + args.steps) * world
@@ -109,7 +116,7 @@ def main():
         ctx.draw_instanced(n)
         if multi:
             ctx.read_pixels_rgba8_device(frame8.data_ptr(), frame8.numel() * 4)
-            sharding.gather_frames(dist, frame8, gathered, dst=0)
+            sharding.gather_frames(dist, frame8 if backend == "nccl" else frame8.cpu(), gathered, dst=0)
 
     def fence():
         ctx.finish()
@@ -139,7 +146,7 @@ def main():
     stats = ctx.stats()
 
     if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -151,14 +158,29 @@ def main():
         timed = {k: v for k, v in stage_ms.items() if v > 0}
         warm = {k: v for k, v in warm_ms.items() if v > 0}
         dom = max(warm, key=warm.get) if warm else None
-        # dominant credited stage (events live in the timed region), priced with its share of the algorithmic bytes; whole frame beside it
+        # The dominant credited stage keeps its HIP events in the timed region.  A stage is `launches` launches of one kernel; achieved =
+        # algorithmic bytes per launch / average launch duration (same ratio as stage bytes / stage time).  HBM traffic per launch comes
+        # from the rocprofv3 --pmc passes of this very command committed under profiles/ (FETCH_SIZE doubled, KiB units; tools/pmc_traffic.py).
+        KERNEL = {"keygen": ("gs4d::k_keygen", 1), "sort": ("gs4d::k_os_pass", 4), "preprocess": ("gs4d::k_preprocess_4d", 1),
+                  "binning": ("gs4d::k_bin_emit", 1), "pairsort": ("gs4d::k_os_pass", 2), "composite": ("gs4d::k_composite<false>", 1)}
         roofline = None
         if timed:
             credited = max(timed, key=timed.get)
+            kname, launches = KERNEL[credited]
             ach = alg[credited] / (timed[credited] * 1e-3) / 1e9
             frame_ach = alg["frame"] / (ms_per_step * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": credited, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        "traffic": None, "kernel_ms": round(timed[credited], 5), "algorithmic_bytes_per_launch": alg[credited],
+            traffic, tsrc = None, None
+            tfile = os.path.join(ROOT, "profiles", {1_000_000: "r01_b_pmc_traffic_c2.json", 10_000_000: "r01_b_pmc_traffic_c3.json"}.get(n, ""))
+            if os.path.isfile(tfile):
+                pm = json.load(open(tfile))
+                hit = [v for k, v in pm.items() if k.startswith(kname)]
+                if hit:
+                    traffic, tsrc = hit[0]["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
+            roofline = {"bound": "hbm", "kernel": kname, "stage": credited, "launches_per_frame": launches,
+                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                        "traffic": traffic, "traffic_source": tsrc,
+                        "kernel_ms": round(timed[credited] / launches, 5), "algorithmic_bytes_per_launch": alg[credited] // launches,
+                        "note": "order, preprocess and raster stages of consecutive frames overlap on three HIP streams: a launch timed in the pipeline is longer than the same launch alone (profiles/)",
                         "slowest_stage": dom,
                         "frame": {"achieved": round(frame_ach, 2), "frac": round(frame_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": alg["frame"]},
                         "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
