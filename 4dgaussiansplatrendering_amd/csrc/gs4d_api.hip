@@ -319,6 +319,7 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if ((e = hipHostGetDevicePointer((void**)&c->host_total_dev, c->host_total, 0)) != hipSuccess) return bail(hipfail(c, e, "hipHostGetDevicePointer"));
     c->dev_err = c->host_total_dev + 4;
     c->depth_sort.err = c->dev_err; c->pair_sort.err = c->dev_err;
+    { bool ordered = false; if ((e = lds_atomic_order_selftest(c->st, &ordered)) != hipSuccess) return bail(hipfail(c, e, "lds_atomic_order_selftest")); c->depth_sort.atomic_rank = c->pair_sort.atomic_rank = ordered; }
     int rc = alloc_fb(c, width, height);
     if (rc) return bail(rc);
     *out = c;

@@ -32,6 +32,7 @@ struct SortScratch {
     bool hist_pending = false;         // the current slot holds a histogram accumulated by a producer kernel, not yet consumed by a sort
     uint32_t epoch = 0;                // tag of the look-back words of the latest pass launch
     uint32_t ticket_base = 0;          // value of the ticket counter (totals[64]) at the start of the next pass launch
+    bool atomic_rank = false;          // LDS-atomic ranking verified on this device (lds_atomic_order_selftest)
     uint32_t* totals = nullptr;                                             // [256] spare words (err word when `err` is not set)
     uint32_t* err = nullptr;                                                // not owned: device word raised when a look-back spin times out
 };
@@ -42,6 +43,7 @@ void sort_scratch_free(SortScratch& s);
 // have_hist: the digit histograms of `keys` were already accumulated (by the kernel that wrote the keys) into sort_hist_slot(s).
 hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist);
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
+hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
 hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist);
 
 // ---- digit histograms for the radix sort, accumulated by whichever kernel produces the keys ----

@@ -223,7 +223,7 @@ __device__ __forceinline__ uint32_t digit_excl_scan(uint32_t v, uint32_t* tmp /*
     return base + inc - v;
 }
 
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, bool ATOMIC_RANK>
 __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
                                                      const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
                                                      uint32_t* status /* [tiles][256] */, u64* gstatus /* [groups][256] */, uint32_t epoch, uint32_t* err,
@@ -285,27 +285,39 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     const uint32_t digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid);     // overlaps the loads above
     if (stamps && tid == 0) stamps[tile * 8 + 1] = wall_clock64();
 
-    const uint64_t lt = (1ull << lane) - 1ull;
-    volatile uint32_t* wc = wcnt[w];
+    if (ATOMIC_RANK) {
+        // rank = value returned by an LDS atomic add on the wave's digit counter.  Stable only because the LDS unit serialises the
+        // lanes of one instruction that hit the same counter in ascending lane order — not an architectural promise, so the
+        // library verifies it on the device at context creation (k_lds_order_test) and uses the ballot form below otherwise.
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const bool valid = (wbase + j * 64u + lane) < n;
-        const uint32_t d = (key[j] >> shift) & 255u;
-        uint64_t m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bal = __ballot(bit);
-            m &= bit ? bal : ~bal;
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool valid = (wbase + j * 64u + lane) < n;
+            const uint32_t d = (key[j] >> shift) & 255u;
+            rank[j] = valid ? atomicAdd(&wcnt[w][d], 1u) : 0u;
         }
-        rank[j] = 0;
-        if (valid) {
-            const uint32_t c = wc[d];
-            rank[j] = c + (uint32_t)__popcll(m & lt);
+    } else {
+        const uint64_t lt = (1ull << lane) - 1ull;
+        volatile uint32_t* wc = wcnt[w];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const bool valid = (wbase + j * 64u + lane) < n;
+            const uint32_t d = (key[j] >> shift) & 255u;
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            rank[j] = 0;
+            if (valid) {
+                const uint32_t c = wc[d];
+                rank[j] = c + (uint32_t)__popcll(m & lt);
+                __builtin_amdgcn_wave_barrier();
+                if ((m & lt) == 0) wc[d] = c + (uint32_t)__popcll(m);
+            }
             __builtin_amdgcn_wave_barrier();
-            if ((m & lt) == 0) wc[d] = c + (uint32_t)__popcll(m);
         }
-        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
     // thread d: counts per wave -> offsets inside the tile's digit-d run; tile count of digit d; publish it at once
@@ -358,6 +370,47 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     if (stamps && tid == 0) stamps[tile * 8 + 5] = wall_clock64();
 }
 
+// Does an LDS atomic add executed by a whole wave return, to the lanes that hit the same address, their rank in ascending lane order?
+__global__ __launch_bounds__(256) void k_lds_order_test(uint32_t* __restrict__ bad) {
+    __shared__ uint32_t cnt[4][256];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    uint32_t errors = 0;
+    for (uint32_t round = 0; round < 96u; ++round) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt[k][tid] = 0u;
+        __syncthreads();
+        const uint32_t bins = round % 6u == 0u ? 1u : round % 6u == 1u ? 2u : round % 6u == 2u ? 3u : round % 6u == 3u ? 7u : round % 6u == 4u ? 64u : 256u;
+        uint32_t x = (blockIdx.x * 256u + tid) * 2654435761u + round * 40503u; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+        const uint32_t d = x % bins;
+        const bool active = ((x >> 20) & 7u) != 0u;              // some lanes sit out, as at the end of an array
+        uint64_t m = __ballot(active);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) { const bool bit = (d >> b) & 1u; const uint64_t bal = __ballot(bit); m &= bit ? bal : ~bal; }
+        if (active) {
+            const uint32_t got = atomicAdd(&cnt[w][d], 1u);
+            const uint32_t want = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (got != want) ++errors;
+            const uint32_t got2 = atomicAdd(&cnt[w][d], 1u);     // a second instruction continues after all lanes of the first
+            if (got2 != (uint32_t)__popcll(m) + want) ++errors;
+        }
+        __syncthreads();
+    }
+    if (errors) atomicAdd(bad, errors);
+}
+
+hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered) {
+    uint32_t* d = nullptr; uint32_t h = 1;
+    hipError_t e = hipMalloc(&d, 4);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d, 0, 4, st)) == hipSuccess) {
+        k_lds_order_test<<<dim3(512), dim3(256), 0, st>>>(d);
+        if ((e = hipGetLastError()) == hipSuccess && (e = hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st)) == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    (void)hipFree(d);
+    *ordered = (e == hipSuccess && h == 0);
+    return e;
+}
+
 hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n) {
     hipError_t e;
     if (s.cap < n) {
@@ -403,7 +456,7 @@ uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError
     return s.hist + (s.flip ? OS_SLOT_WORDS : 0);
 }
 
-template <int THREADS, int ITEMS>
+template <int THREADS, int ITEMS, bool ATOMIC_RANK>
 static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist) {
     const uint32_t tile_keys = THREADS * ITEMS;
     const uint32_t tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
@@ -433,7 +486,7 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
             if ((e = hipMemsetAsync(status, 0, (s.hist_cap - 2 * OS_SLOT_WORDS) * 4, st)) != hipSuccess) return e;
             ++s.epoch;
         }
-        k_os_pass<THREADS, ITEMS><<<dim3(tiles), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, gstatus, s.epoch & 0x3FFFFFFFu,
+        k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(tiles), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, gstatus, s.epoch & 0x3FFFFFFFu,
                                                                          s.err ? s.err : s.totals, s.totals + 64, s.ticket_base, (stampf && p == stamp_pass) ? stamps : nullptr);
         s.ticket_base += tiles;               // every workgroup of the launch draws exactly one ticket
     }
@@ -457,14 +510,18 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
     if (passes < 2) passes = 2;                       // an even number of executed passes always exists (see os_schedule)
     static const int knob = getenv("GS4D_SORT_SHAPE") ? atoi(getenv("GS4D_SORT_SHAPE")) : 0;      // tuning knob (experiments only)
     const int shape = knob ? knob : (n <= ((size_t)3 << 20) ? 2 : 5);     // 4096-key tiles for small sorts, 8192-key tiles beyond
+    static const int rank_knob = getenv("GS4D_SORT_RANK") ? atoi(getenv("GS4D_SORT_RANK")) : 0;   // tuning knob: 1 = ballot ranking, 2 = LDS-atomic ranking
+    const bool atomic_rank = rank_knob ? rank_knob == 2 : s.atomic_rank;
+#define GS4D_OS(T, I) (atomic_rank ? onesweep<T, I, true>(st, s, keys, vals, n, n_dev, passes, have_hist) : onesweep<T, I, false>(st, s, keys, vals, n, n_dev, passes, have_hist))
     switch (shape) {
-    case 1: return onesweep<256, 8>(st, s, keys, vals, n, n_dev, passes, have_hist);
-    case 2: return onesweep<512, 8>(st, s, keys, vals, n, n_dev, passes, have_hist);
-    case 3: return onesweep<1024, 8>(st, s, keys, vals, n, n_dev, passes, have_hist);
-    case 4: return onesweep<256, 16>(st, s, keys, vals, n, n_dev, passes, have_hist);
-    case 5: return onesweep<512, 16>(st, s, keys, vals, n, n_dev, passes, have_hist);
-    default: return onesweep<512, 4>(st, s, keys, vals, n, n_dev, passes, have_hist);
+    case 1: return GS4D_OS(256, 8);
+    case 2: return GS4D_OS(512, 8);
+    case 3: return GS4D_OS(1024, 8);
+    case 4: return GS4D_OS(256, 16);
+    case 5: return GS4D_OS(512, 16);
+    default: return GS4D_OS(512, 4);
     }
+#undef GS4D_OS
 }
 
 } // namespace gs4d
