@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <cmath>
 
 using namespace gs4d;
 
@@ -25,6 +26,8 @@ struct Buffer {
     float4* soa = nullptr;         // lazily built SoA shadow of 96-B SplatData records
     size_t soa_n = 0;
     uint64_t soa_version = ~0ull;
+    uint32_t* bbox_dev = nullptr;  // 16 words: bounding box of pos / mu_t / velocity, reduced by the repack kernel
+    double bb_lo[7] = { 0 }, bb_hi[7] = { 0 }; bool bb_ok = false;
     bool alive = false;
 };
 
@@ -128,8 +131,18 @@ int ensure_soa(gs4d_ctx* c, Buffer& b) {
         if (n) HIPCHK(c, hipMalloc(&b.soa, n * 96));
         b.soa_n = n;
     }
-    HIPCHK(c, launch_soa_repack(c->st, (const float*)b.d, n, b.soa));
+    // bounding box of everything the sort key depends on (upload-time work: one small read-back per refresh)
+    uint32_t init[16]; for (int i = 0; i < 16; ++i) init[i] = i < 7 ? 0xFFFFFFFFu : 0u;
+    if (!b.bbox_dev) HIPCHK(c, hipMalloc(&b.bbox_dev, 64));
+    HIPCHK(c, hipMemcpyAsync(b.bbox_dev, init, 64, hipMemcpyHostToDevice, c->st));
+    HIPCHK(c, launch_soa_repack(c->st, (const float*)b.d, n, b.soa, b.bbox_dev));
     HIPCHK(c, hipEventRecord(c->ev_soa, c->st));
+    uint32_t got[16];
+    HIPCHK(c, hipMemcpyAsync(got, b.bbox_dev, 64, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(c, hipStreamSynchronize(c->st));
+    auto ord2f = [](uint32_t u) { u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &u, 4); return (double)f; };
+    b.bb_ok = n > 0 && got[14] == 0;
+    for (int k = 0; k < 7; ++k) { b.bb_lo[k] = ord2f(got[k]); b.bb_hi[k] = ord2f(got[7 + k]); if (!(b.bb_lo[k] <= b.bb_hi[k])) b.bb_ok = false; }
     b.soa_version = b.version;
     return GS4D_OK;
 }
@@ -333,7 +346,7 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (c->rs) (void)hipStreamSynchronize(c->rs);
     if (c->ps) (void)hipStreamSynchronize(c->ps);
     if (c->order_copy) (void)hipFree(c->order_copy);
-    for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); }
+    for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); if (b.bbox_dev) (void)hipFree(b.bbox_dev); }
     if (c->fb) (void)hipFree(c->fb);
     for (int i = 0; i < 2; ++i) { if (c->proj2[i]) (void)hipFree(c->proj2[i]); if (c->rects2[i]) (void)hipFree(c->rects2[i]); }
     if (c->pair_keys) (void)hipFree(c->pair_keys);
@@ -411,6 +424,7 @@ int gs4d_buffer_destroy(gs4d_ctx* c, gs4d_buf b) {
     { int rc = resolve_pending(c); if (rc) return rc; rc = sync_all(c); if (rc) return rc; }
     if (B->d) (void)hipFree(B->d);
     if (B->soa) (void)hipFree(B->soa);
+    if (B->bbox_dev) (void)hipFree(B->bbox_dev);
     *B = Buffer();
     for (auto& s : c->slots) if (s == b) s = 0;     // a deleted buffer is unbound
     if (c->last_order == b) c->last_order = 0;
@@ -502,8 +516,28 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     hipError_t he = hipSuccess;
     uint32_t* kh = sort_hist_slot(c->st, c->depth_sort, n, &he);
     if (!kh) return hipfail(c, he, "sort_hist_slot");
+    // A proven lower bound of every key (1 / farthest possible distance, from the bounding box of the records) is subtracted inside
+    // the sort's digit extraction: when the keys span less than 2^24 bit patterns above it (camera outside the cloud, far/near < 4)
+    // the top digit becomes constant and its pass is skipped on the device.  k_keygen re-checks the bound for every key.
+    uint32_t bias = 0;
+    if (key_mode == GS4D_KEY_REF_INV_EUCLID && D->bb_ok) {          // the box covers all records of the buffer, a superset of the n keyed
+        const double c_lo = (double)t - D->bb_hi[3], c_hi = (double)t - D->bb_lo[3];
+        double d2 = 0.0;
+        for (int ax = 0; ax < 3; ++ax) {
+            const double v_lo = D->bb_lo[4 + ax], v_hi = D->bb_hi[4 + ax];
+            const double p1 = v_lo * c_lo, p2 = v_lo * c_hi, p3 = v_hi * c_lo, p4 = v_hi * c_hi;
+            const double m_lo = D->bb_lo[ax] + std::min(std::min(p1, p2), std::min(p3, p4));
+            const double m_hi = D->bb_hi[ax] + std::max(std::max(p1, p2), std::max(p3, p4));
+            const double far = std::max(std::fabs(m_lo - (double)cam[ax]), std::fabs(m_hi - (double)cam[ax]));
+            d2 += far * far;
+        }
+        const double dmax = std::sqrt(d2) * (1.0 + 1e-4) + 1e-3;       // generous against float rounding in the kernel's own arithmetic
+        const float lb = (float)((1.0 / dmax) * (1.0 - 1e-5));
+        if (std::isfinite(dmax) && lb > 0.0f && std::isfinite(lb)) memcpy(&bias, &lb, 4);
+    }
     StageTimer tm(c, GS4D_T_KEYGEN);
-    HIPCHK(c, launch_keygen(c->st, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d, kh));
+    HIPCHK(c, launch_keygen(c->st, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d, kh, bias, c->dev_err));
+    c->depth_sort.hist_bias = bias;
     K->version++; I->version++;
     c->kg_buf = keys; c->kg_ver = K->version; c->kg_n = n;
     return GS4D_OK;
@@ -548,7 +582,7 @@ int gs4d_finish(gs4d_ctx* c) {
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
     rc = sync_all(c); if (rc) return rc;
-    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "a bounded device-side wait timed out (radix sort / binning look-back): results are invalid");
+    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "device-side check failed (a bounded look-back wait timed out, or a sort key fell below its proven bound): results are invalid");
     return GS4D_OK;
 }
 
@@ -560,7 +594,7 @@ int gs4d_read_pixels(gs4d_ctx* c, float* rgba, size_t bytes) {
     rc = materialise_fb(c); if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(rgba, c->fb, bytes, hipMemcpyDeviceToHost, c->rs));
     HIPCHK(c, hipStreamSynchronize(c->rs));
-    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "a bounded device-side wait timed out (radix sort / binning look-back): results are invalid");
+    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "device-side check failed (a bounded look-back wait timed out, or a sort key fell below its proven bound): results are invalid");
     return GS4D_OK;
 }
 

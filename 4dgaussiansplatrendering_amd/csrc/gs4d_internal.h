@@ -30,6 +30,7 @@ struct SortScratch {
     uint32_t* hist = nullptr; size_t hist_cap = 0;                          // two [OS_REPL][4][256] digit-histogram slots (alternating), then the look-back words
     int flip = 0;
     bool hist_pending = false;         // the current slot holds a histogram accumulated by a producer kernel, not yet consumed by a sort
+    uint32_t hist_bias = 0;            // ... of (key - hist_bias): a lower bound of all keys, which makes the high digits constant (and their passes skipped)
     uint32_t epoch = 0;                // tag of the look-back words of the latest pass launch
     uint32_t ticket_base = 0;          // value of the ticket counter (totals[64]) at the start of the next pass launch
     bool atomic_rank = false;          // LDS-atomic ranking verified on this device (lds_atomic_order_selftest)
@@ -44,7 +45,8 @@ void sort_scratch_free(SortScratch& s);
 hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist);
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
 hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
-hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist);
+hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
+                         uint32_t bias, uint32_t* err);
 
 // ---- digit histograms for the radix sort, accumulated by whichever kernel produces the keys ----
 constexpr int OS_MAX_PASSES = 4;
@@ -87,7 +89,7 @@ __device__ __forceinline__ void os_hist_flush(uint32_t (*h)[256], uint32_t* __re
 #endif
 
 // ---- preprocess.hip ----
-hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* 6 planes of n float4 */);
+hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* 6 planes of n float4 */, uint32_t* bbox /* [16], preset: min = ~0, max = 0 */);
 // Each preprocess launch also writes the compact pixel rectangle of every record.
 struct PreOut { float4* proj; uint2* rects; };
 hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& u, int W, int H, PreOut out);

@@ -12,7 +12,12 @@
 namespace gs4d {
 
 // AoS 96-B SplatData (Scenes.h:22-37) -> 6 planes of float4: pos, col, sig[0], sig[1], sig[2], sig[3]
-__global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ soa) {
+// float <-> unsigned with the same order, for atomicMin/atomicMax on floats
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+
+// Also reduces the bounding box of what the sort key depends on — position, mu_t and the velocity column sig[3].xyz
+// (Scenes.h:28-36) — into bbox[0..6] = min, bbox[7..13] = max (order-preserving uint form), bbox[14] = non-finite input seen.
+__global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ soa, uint32_t* __restrict__ bbox) {
     // one wave moves 64 records = 384 float4, read fully coalesced, written as 6 x 64 contiguous float4
     __shared__ float4 stage[4][384];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
@@ -24,15 +29,36 @@ __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ a
         if (f < nrec * 6u) stage[w][f] = aos[(size_t)rec0 * 6u + f];
     }
     __syncthreads();
-    if (lane < nrec) {
+    float q[7];
+    bool have = lane < nrec;
+    if (have) {
 #pragma unroll
         for (int p = 0; p < 6; ++p) soa[(size_t)p * n + rec0 + lane] = stage[w][lane * 6u + p];
+        const float4 ps = stage[w][lane * 6u + 0], s3 = stage[w][lane * 6u + 5];
+        q[0] = ps.x; q[1] = ps.y; q[2] = ps.z; q[3] = ps.w; q[4] = s3.x; q[5] = s3.y; q[6] = s3.z;
+    }
+    bool bad = false;
+    uint32_t lo[7], hi[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const bool fin = have && isfinite(q[k]);
+        bad = bad || (have && !fin);
+        lo[k] = fin ? f2ord(q[k]) : 0xFFFFFFFFu;
+        hi[k] = fin ? f2ord(q[k]) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo[k] = min(lo[k], (uint32_t)__shfl_xor(lo[k], off, 64)); hi[k] = max(hi[k], (uint32_t)__shfl_xor(hi[k], off, 64)); }
+    }
+    const bool anybad = __ballot(bad) != 0ull;
+    if (lane == 0 && nrec) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { atomicMin(&bbox[k], lo[k]); atomicMax(&bbox[7 + k], hi[k]); }
+        if (anybad) atomicOr(&bbox[14], 1u);
     }
 }
 
-hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa) {
+hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa, uint32_t* bbox) {
     if (n == 0) return hipSuccess;
-    k_soa_repack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa);
+    k_soa_repack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox);
     return hipGetLastError();
 }
 

@@ -25,7 +25,8 @@ namespace gs4d {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, const float4* __restrict__ sig3, uint32_t n, float t,
                                                 float camx, float camy, float camz, float4 vrow2 /* view row 2: V[2],V[6],V[10],V[14] */, int key_mode,
-                                                float* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ ghist /* digit histograms of the keys, for the sort */) {
+                                                float* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ ghist /* digit histograms of (key - bias), for the sort */,
+                                                uint32_t bias /* host-proven lower bound of every key's bit pattern */, uint32_t* __restrict__ err) {
     __shared__ uint32_t h[OS_MAX_PASSES][256];
     os_hist_clear(h, threadIdx.x);
     __syncthreads();
@@ -53,17 +54,20 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, 
             keys[i] = key;
             idx[i] = i;
         }
-        os_hist_add(h, __float_as_uint(key), in, OS_MAX_PASSES);
+        const uint32_t kb = __float_as_uint(key);
+        if (in && kb < bias) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the bound did not hold: reported, never silently mis-sorted
+        os_hist_add(h, kb - bias, in, OS_MAX_PASSES);
     }
     __syncthreads();
     os_hist_flush(h, ghist, OS_MAX_PASSES, threadIdx.x);
 }
 
-hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist) {
+hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
+                         uint32_t bias, uint32_t* err) {
     if (n == 0) return hipSuccess;
     float4 vr = make_float4(view[2], view[6], view[10], view[14]);
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);     // grid-stride: bounds the histogram flush to 1024 workgroups
-    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist);
+    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist, bias, err);
     return hipGetLastError();
 }
 
@@ -227,7 +231,7 @@ template <int THREADS, int ITEMS, bool ATOMIC_RANK>
 __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
                                                      const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
                                                      uint32_t* status /* [tiles][256] */, u64* gstatus /* [groups][256] */, uint32_t epoch, uint32_t* err,
-                                                     uint32_t* ticket, uint32_t ticket_base, u64* stamps /* tuning aid, may be null */) {
+                                                     uint32_t* ticket, uint32_t ticket_base, uint32_t bias, u64* stamps /* tuning aid, may be null */) {
     constexpr uint32_t TILE_KEYS = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
     static_assert(TILE_KEYS < (1u << 14), "tile-level look-back words carry 14-bit counts");
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const bool valid = (wbase + j * 64u + lane) < n;
-            const uint32_t d = (key[j] >> shift) & 255u;
+            const uint32_t d = ((key[j] - bias) >> shift) & 255u;
             rank[j] = valid ? atomicAdd(&wcnt[w][d], 1u) : 0u;
         }
     } else {
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const bool valid = (wbase + j * 64u + lane) < n;
-            const uint32_t d = (key[j] >> shift) & 255u;
+            const uint32_t d = ((key[j] - bias) >> shift) & 255u;
             uint64_t m = __ballot(valid);
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if ((wbase + j * 64u + lane) < n) {                       // stable: wave-major, item-major, lane order == memory order
-            const uint32_t d = (key[j] >> shift) & 255u;
+            const uint32_t d = ((key[j] - bias) >> shift) & 255u;
             const uint32_t l = loff[d] + wcnt[w][d] + rank[j];
             skeys[l] = key[j];
             svals[l] = val[j];
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         const uint32_t l = j * THREADS + tid;
         if (l < tcount) {
             const uint32_t k = skeys[l];
-            const uint32_t d = (k >> shift) & 255u;
+            const uint32_t d = ((k - bias) >> shift) & 255u;
             const uint32_t o = gpos[d] + (l - loff[d]);
             keys_out[o] = k;
             vals_out[o] = svals[l];
@@ -463,6 +467,8 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     uint32_t* ghist = s.hist + (s.flip ? OS_SLOT_WORDS : 0);
     uint32_t* ghist_other = s.hist + (s.flip ? 0 : OS_SLOT_WORDS);
     hipError_t e;
+    const uint32_t bias = have_hist ? s.hist_bias : 0u;
+    s.hist_bias = 0;
     if (!have_hist) {
         if (s.hist_pending) { if ((e = hipMemsetAsync(ghist, 0, OS_SLOT_WORDS * 4, st)) != hipSuccess) return e; }   // someone else's histogram sits in the slot
         const uint32_t hist_blocks = (uint32_t)std::min<size_t>((n / 16 + 255) / 256 + 1, 256);          // few workgroups: each flushes 256 global atomics per pass
@@ -487,7 +493,7 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
             ++s.epoch;
         }
         k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(tiles), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, gstatus, s.epoch & 0x3FFFFFFFu,
-                                                                         s.err ? s.err : s.totals, s.totals + 64, s.ticket_base, (stampf && p == stamp_pass) ? stamps : nullptr);
+                                                                         s.err ? s.err : s.totals, s.totals + 64, s.ticket_base, bias, (stampf && p == stamp_pass) ? stamps : nullptr);
         s.ticket_base += tiles;               // every workgroup of the launch draws exactly one ticket
     }
     if (stampf && stamps) {   // tuning aid: dump per-tile wall-clock stamps (100 MHz) of one pass
