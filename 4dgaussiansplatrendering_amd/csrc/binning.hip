@@ -11,11 +11,13 @@
 // Counting, scanning and emitting are ONE launch (chained scan over workgroup totals); the per-record pixel rectangles are read
 // from a compact 8-byte array (L2/Infinity-Cache resident) instead of the 64-byte projected records.
 #include "gs4d_internal.h"
+#include <cstdlib>
 
 namespace gs4d {
 
-constexpr int BIN_THREADS = 256;
-constexpr int BIN_ITEMS = 4;
+constexpr int BIN_THREADS = 512;     // 4096 instances per workgroup: one ticket (a same-address atomic, ~11 ns each chip-wide) per 4096
+constexpr int BIN_ITEMS = 8;
+constexpr int BIN_WAVES = BIN_THREADS / 64;
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 #pragma unroll
@@ -26,17 +28,17 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-// exclusive scan over the 256 threads of a block; returns the exclusive prefix, total = block sum
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /* __shared__[4] */, uint32_t& total) {
+// exclusive scan over the threads of a block; returns the exclusive prefix, total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /* __shared__[BIN_WAVES] */, uint32_t& total) {
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
     uint32_t inc = wave_incl_scan(v);
     __syncthreads();                      // protect wsum from the previous round
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    uint32_t base = 0;
+    uint32_t base = 0, tot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if ((unsigned)k < w) base += wsum[k];
-    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    for (int k = 0; k < BIN_WAVES; ++k) { const uint32_t s = wsum[k]; if ((unsigned)k < w) base += s; tot += s; }
+    total = tot;
     return base + inc - v;
 }
 
@@ -51,7 +53,7 @@ __device__ __forceinline__ void emit_tiles(const Rect& r, uint32_t off, uint32_t
         const uint32_t id = ty * tiles_x + tx;
         pk[off + j] = id;
         pv[off + j] = rec;
-        for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(id >> (8 * p)) & 255u], 1u);
+        if (h) for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(id >> (8 * p)) & 255u], 1u);
     }
 }
 
@@ -69,14 +71,14 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
-                                                          unsigned long long* status, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
+                                                          unsigned long long* status, unsigned long long* gstatus, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
                                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
-                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base) {
-    __shared__ uint32_t wsum[4];
+                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base, int dbg) {
+    __shared__ uint32_t wsum[BIN_WAVES];
     __shared__ unsigned long long s_prefix;
     __shared__ uint32_t s_blk;
     __shared__ uint32_t h[OS_MAX_PASSES][256];
-    os_hist_clear(h, threadIdx.x);
+    if (threadIdx.x < 256u) os_hist_clear(h, threadIdx.x);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // the slice of instances is handed out by ticket (start order), so the look-back only ever waits for running workgroups
     if (tid == 0) s_blk = atomicAdd(ticket, 1u) - ticket_base;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
             rec[j] = order ? order[k] : k;
             if (order_copy) order_copy[k] = rec[j];      // the draw keeps its own copy: the caller may refill the buffer for the next frame
             if (rec[j] < nrecords) {              // an index past the bound SSBO: GL would read undefined data; we draw nothing
-                const uint2 rr = rects[rec[j]];
+                const uint2 rr = (dbg & 1) ? make_uint2((k % 1900u) | ((k % 1070u) << 16), ((k % 1900u) + 2u) | (((k % 1070u) + 2u) << 16)) : rects[rec[j]];
                 const uint32_t x0 = rr.x & 0xFFFFu, y0 = rr.x >> 16, x1 = rr.y & 0xFFFFu, y1 = rr.y >> 16;
                 if (x0 <= x1 && y0 <= y1) {
                     r[j].tx0 = x0 / TILE; r[j].ty0 = y0 / TILE; r[j].tx1 = x1 / TILE; r[j].ty1 = y1 / TILE;
@@ -104,32 +106,44 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
     }
 #pragma unroll
     for (int j = 0; j < BIN_ITEMS; ++j) { uint32_t tot; off[j] = run + block_excl_scan(r[j].count, wsum, tot); run += tot; }
-    // publish this workgroup's total, look back for the exclusive prefix (wave 0, 64 predecessors per step)
+    // Publish this workgroup's total, then look back for the exclusive prefix (wave 0).  Two levels, as in the radix sort: the 64
+    // workgroups of a group are read in one wave-wide load; the last workgroup of a group also publishes the group's total (AGG)
+    // and, once it knows it, the inclusive prefix at the end of the group (INCL).  When ~1000 workgroups start together a
+    // one-level walk needs one memory round trip per 64 predecessors; this needs two or three in all.
     if (tid < 64) {
         unsigned long long prefix = 0;
-        if (blk == 0) { if (lane == 0) __hip_atomic_store(status, bs_word(epoch, 2ull, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-        else {
-            if (lane == 0) __hip_atomic_store(status + blk, bs_word(epoch, 1ull, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int64_t p = (int64_t)blk - 1;
-            uint32_t spins = 0;
+        const uint32_t grp = blk / 64u, r = blk % 64u;
+        uint32_t spins = 0;
+        bool failed = false;
+        if (lane == 0) __hip_atomic_store(status + blk, bs_word(epoch, 1ull, run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r > 0) {                                              // workgroups grp*64 .. blk-1
             while (true) {
-                const int64_t idx = p - (int64_t)lane;
-                const unsigned long long v = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bs_word(epoch, 2ull, 0ull);   // before workgroup 0: inclusive 0
-                const uint32_t f = bs_flag(v, epoch);
-                const uint64_t none = __ballot(f == 0u), incl = __ballot(f == 2u);
-                const uint64_t low = incl & (0ull - incl);                                     // nearest INCL
-                const uint64_t upto = incl ? (low | (low - 1ull)) : ~0ull;                       // lanes up to and including it
-                if (none & upto) {                          // a needed word is not published yet
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 21)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-                    continue;
-                }
-                prefix += wave_sum_u64(((upto >> lane) & 1ull) ? (v & BS_VAL) : 0ull);
-                if (incl) break;
-                p -= 64;
+                const unsigned long long v = lane < r ? __hip_atomic_load(status + (blk - 1u - lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bs_word(epoch, 1ull, 0ull);
+                if (__ballot(bs_flag(v, epoch) == 0u) == 0ull) { prefix = wave_sum_u64(v & BS_VAL); break; }
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 21)) { failed = true; break; }
             }
-            if (lane == 0) __hip_atomic_store(status + blk, bs_word(epoch, 2ull, prefix + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (r == 63u && lane == 0) __hip_atomic_store(gstatus + grp, bs_word(epoch, 1ull, prefix + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int64_t p = (int64_t)grp - 1;
+        while (p >= 0 && !failed) {                              // groups before this one, 64 per step, until an INCL
+            const int64_t idx = p - (int64_t)lane;
+            const unsigned long long v = idx >= 0 ? __hip_atomic_load(gstatus + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : bs_word(epoch, 2ull, 0ull);   // before group 0: inclusive 0
+            const uint32_t f = bs_flag(v, epoch);
+            const uint64_t none = __ballot(f == 0u), incl = __ballot(f == 2u);
+            const uint64_t low = incl & (0ull - incl);                                     // nearest INCL
+            const uint64_t upto = incl ? (low | (low - 1ull)) : ~0ull;                       // lanes up to and including it
+            if (none & upto) {                                    // a needed word is not published yet
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 21)) failed = true;
+                continue;
+            }
+            prefix += wave_sum_u64(((upto >> lane) & 1ull) ? (v & BS_VAL) : 0ull);
+            if (incl) break;
+            p -= 64;
+        }
+        if (failed && lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (r == 63u && lane == 0) __hip_atomic_store(gstatus + grp, bs_word(epoch, 2ull, prefix + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) {
             s_prefix = prefix;
             if (blk == gridDim.x - 1) {                     // the last workgroup knows the grand total
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
         const bool fits = o64 + r[j].count <= (unsigned long long)cap;      // entries beyond the capacity are not written; the draw is re-run
         const uint32_t o = (uint32_t)o64;
         const bool big = fits && r[j].count > 32u;
-        if (fits && !big) emit_tiles(r[j], o, rec[j], tiles_x, 0u, 1u, pk, pv, h, passes);
+        if (fits && !big && !(dbg & 4)) emit_tiles(r[j], o, rec[j], tiles_x, 0u, 1u, pk, pv, (dbg & 2) ? nullptr : h, passes);
         // large footprints: the whole wave writes one splat's entries
         uint64_t m = __ballot(big);
         while (m) {
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
         }
     }
     __syncthreads();
-    os_hist_flush(h, ghist, passes, tid);
+    if (tid < 256u) os_hist_flush(h, ghist, passes, tid);
 }
 
 __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict__ pk, const uint32_t* __restrict__ total, uint32_t ntiles, uint32_t* __restrict__ ranges) {
@@ -195,9 +209,10 @@ hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size
         if (b.ranges) { (void)hipStreamSynchronize(st); (void)hipFree(b.ranges); }
         const size_t nb2 = nb > b.block_cap ? nb : b.block_cap, nt2 = ntiles > b.tiles_cap ? ntiles : b.tiles_cap;
         b.ranges = nullptr; b.status = nullptr; b.block_cap = b.tiles_cap = 0;
-        // one allocation: [ranges: 2*tiles u32][status: blocks u64]
-        if ((e = hipMalloc(&b.ranges, nt2 * 8 + nb2 * 8)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(b.ranges, 0, nt2 * 8 + nb2 * 8, st)) != hipSuccess) return e;    // ranges stay zero between draws: the composite clears what it reads
+        // one allocation: [ranges: 2*tiles u32][status: blocks u64][group status: blocks/64 u64]
+        const size_t ng = nb2 / 64 + 2;
+        if ((e = hipMalloc(&b.ranges, nt2 * 8 + (nb2 + ng) * 8)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(b.ranges, 0, nt2 * 8 + (nb2 + ng) * 8, st)) != hipSuccess) return e;    // ranges stay zero between draws: the composite clears what it reads
         b.status = reinterpret_cast<unsigned long long*>(b.ranges + 2 * nt2);
         b.block_cap = nb2; b.tiles_cap = nt2;
     }
@@ -213,13 +228,14 @@ void bin_scratch_free(BinScratch& b) {
 hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
                           uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host) {
     (void)tiles_y;
+    static const int dbg = getenv("GS4D_EMIT_DBG") ? atoi(getenv("GS4D_EMIT_DBG")) : 0;      // tuning aid (ablation): 1 no rect gather, 2 no histogram, 4 no writes
     if (++b.epoch >= (1u << 22)) {            // epoch wrap: forget every old word
-        hipError_t e = hipMemsetAsync(b.status, 0, b.block_cap * 8, st);
+        hipError_t e = hipMemsetAsync(b.status, 0, (b.block_cap + b.block_cap / 64 + 2) * 8, st);
         if (e != hipSuccess) return e;
         b.epoch = 1;
     }
     const uint32_t nb = (uint32_t)((ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch, b.total + 8, b.ticket_base);
+    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.status + b.block_cap, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch, b.total + 8, b.ticket_base, dbg);
     b.ticket_base += nb;
     return hipGetLastError();
 }
