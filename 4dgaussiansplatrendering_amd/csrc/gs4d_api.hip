@@ -498,7 +498,7 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
     const bool have_hist = c->depth_sort.hist_pending && keys == c->kg_buf && K->version == c->kg_ver && n == c->kg_n;
     StageTimer t(c, GS4D_T_SORT);
-    HIPCHK(c, radix_sort_pairs(c->st, c->depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, 32, have_hist));
+    HIPCHK(c, radix_sort_pairs(c->st, c->depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, have_hist ? c->depth_sort.hist_bits : 32, have_hist));
     K->version++; V->version++;
     return GS4D_OK;
 }
@@ -519,10 +519,12 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     // A proven lower bound of every key (1 / farthest possible distance, from the bounding box of the records) is subtracted inside
     // the sort's digit extraction: when the keys span less than 2^24 bit patterns above it (camera outside the cloud, far/near < 4)
     // the top digit becomes constant and its pass is skipped on the device.  k_keygen re-checks the bound for every key.
-    uint32_t bias = 0;
+    // When the camera is provably outside the box the same reasoning gives an upper bound, hence the number of key bits above the
+    // bias: with <= 24 the sort is launched with three passes instead of four (no launch for the constant digit at all).
+    uint32_t bias = 0, span = 0xFFFFFFFFu;
     if (key_mode == GS4D_KEY_REF_INV_EUCLID && D->bb_ok) {          // the box covers all records of the buffer, a superset of the n keyed
         const double c_lo = (double)t - D->bb_hi[3], c_hi = (double)t - D->bb_lo[3];
-        double d2 = 0.0;
+        double d2 = 0.0, n2 = 0.0;
         for (int ax = 0; ax < 3; ++ax) {
             const double v_lo = D->bb_lo[4 + ax], v_hi = D->bb_hi[4 + ax];
             const double p1 = v_lo * c_lo, p2 = v_lo * c_hi, p3 = v_hi * c_lo, p4 = v_hi * c_hi;
@@ -530,14 +532,25 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
             const double m_hi = D->bb_hi[ax] + std::max(std::max(p1, p2), std::max(p3, p4));
             const double far = std::max(std::fabs(m_lo - (double)cam[ax]), std::fabs(m_hi - (double)cam[ax]));
             d2 += far * far;
+            const double near = std::max(0.0, std::max(m_lo - (double)cam[ax], (double)cam[ax] - m_hi));
+            n2 += near * near;
         }
         const double dmax = std::sqrt(d2) * (1.0 + 1e-4) + 1e-3;       // generous against float rounding in the kernel's own arithmetic
         const float lb = (float)((1.0 / dmax) * (1.0 - 1e-5));
-        if (std::isfinite(dmax) && lb > 0.0f && std::isfinite(lb)) memcpy(&bias, &lb, 4);
+        if (std::isfinite(dmax) && lb > 0.0f && std::isfinite(lb)) {
+            memcpy(&bias, &lb, 4);
+            const double dmin = std::sqrt(n2) * (1.0 - 1e-4) - 1e-3;
+            if (dmin > 0.0) {
+                const float ub = (float)((1.0 / dmin) * (1.0 + 1e-5));
+                uint32_t ubits; memcpy(&ubits, &ub, 4);
+                if (std::isfinite(ub) && ubits >= bias) span = ubits - bias;
+            }
+        }
     }
     StageTimer tm(c, GS4D_T_KEYGEN);
-    HIPCHK(c, launch_keygen(c->st, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d, kh, bias, c->dev_err));
+    HIPCHK(c, launch_keygen(c->st, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d, kh, bias, span, c->dev_err));
     c->depth_sort.hist_bias = bias;
+    c->depth_sort.hist_bits = span < (1u << 8) ? 8 : span < (1u << 16) ? 16 : span < (1u << 24) ? 24 : 32;
     K->version++; I->version++;
     c->kg_buf = keys; c->kg_ver = K->version; c->kg_n = n;
     return GS4D_OK;

@@ -30,6 +30,7 @@ struct SortScratch {
     uint32_t* hist = nullptr; size_t hist_cap = 0;                          // two [OS_REPL][4][256] digit-histogram slots (alternating), then the look-back words
     int flip = 0;
     bool hist_pending = false;         // the current slot holds a histogram accumulated by a producer kernel, not yet consumed by a sort
+    int hist_bits = 32;                // host-proven width of (key - hist_bias): passes above it are not even launched
     uint32_t hist_bias = 0;            // ... of (key - hist_bias): a lower bound of all keys, which makes the high digits constant (and their passes skipped)
     uint32_t epoch = 0;                // tag of the look-back words of the latest pass launch
     uint32_t ticket_base = 0;          // value of the ticket counter (totals[64]) at the start of the next pass launch
@@ -46,7 +47,7 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
 hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
 hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
-                         uint32_t bias, uint32_t* err);
+                         uint32_t bias, uint32_t span, uint32_t* err);
 
 // ---- digit histograms for the radix sort, accumulated by whichever kernel produces the keys ----
 constexpr int OS_MAX_PASSES = 4;

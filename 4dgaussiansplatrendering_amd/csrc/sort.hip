@@ -26,7 +26,7 @@ namespace gs4d {
 __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, const float4* __restrict__ sig3, uint32_t n, float t,
                                                 float camx, float camy, float camz, float4 vrow2 /* view row 2: V[2],V[6],V[10],V[14] */, int key_mode,
                                                 float* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ ghist /* digit histograms of (key - bias), for the sort */,
-                                                uint32_t bias /* host-proven lower bound of every key's bit pattern */, uint32_t* __restrict__ err) {
+                                                uint32_t bias /* host-proven lower bound of every key's bit pattern */, uint32_t span /* ... and of (key - bias) from above */, uint32_t* __restrict__ err) {
     __shared__ uint32_t h[OS_MAX_PASSES][256];
     os_hist_clear(h, threadIdx.x);
     __syncthreads();
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, 
             idx[i] = i;
         }
         const uint32_t kb = __float_as_uint(key);
-        if (in && kb < bias) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the bound did not hold: reported, never silently mis-sorted
+        if (in && (kb < bias || kb - bias > span)) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the bound did not hold: reported, never silently mis-sorted
         os_hist_add(h, kb - bias, in, OS_MAX_PASSES);
     }
     __syncthreads();
@@ -63,11 +63,11 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, 
 }
 
 hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
-                         uint32_t bias, uint32_t* err) {
+                         uint32_t bias, uint32_t span, uint32_t* err) {
     if (n == 0) return hipSuccess;
     float4 vr = make_float4(view[2], view[6], view[10], view[14]);
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);     // grid-stride: bounds the histogram flush to 1024 workgroups
-    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist, bias, err);
+    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist, bias, span, err);
     return hipGetLastError();
 }
 
