@@ -60,6 +60,7 @@ def _load():
         "gs4d_finish": (i32, [vp]),
         "gs4d_set_profiling": (i32, [vp, i32]),
         "gs4d_get_timings": (i32, [vp, vp]),
+        "gs4d_get_timeline": (i32, [vp, vp, i32, vp]),
         "gs4d_get_stats": (i32, [vp, vp]),
         "gs4d_debug_read_projected": (i32, [vp, vp, sz]),
         "gs4d_host_look_at": (None, [vp, vp, vp, vp]),
@@ -301,6 +302,13 @@ class Context:
         ms = np.zeros(len(STAGES), np.float32)
         self._chk(_lib.gs4d_get_timings(self._h, _ptr(ms)))
         return dict(zip(STAGES, (float(x) for x in ms)))
+
+    def timeline(self, max_frames=128):
+        """[frames, stages, 2] start/end (ms since the first timed stage of frame 0) of the frames recorded so far; -1 where not run."""
+        ms = np.full((max_frames, len(STAGES), 2), -1.0, np.float32)
+        n = C.c_int(0)
+        self._chk(_lib.gs4d_get_timeline(self._h, _ptr(ms), max_frames, C.byref(n)))
+        return ms[:n.value]
 
     def stats(self):
         st = np.zeros(4, np.uint64)

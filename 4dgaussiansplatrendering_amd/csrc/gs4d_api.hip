@@ -10,6 +10,7 @@
 // validation of a draw's tile-list capacity, which is deferred to the next call that could observe it (see resolve_pending).
 #include "gs4d_internal.h"
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <algorithm>
@@ -28,6 +29,8 @@ struct Buffer {
     uint64_t soa_version = ~0ull;
     uint32_t* bbox_dev = nullptr;  // 16 words: bounding box of pos / mu_t / velocity, reduced by the repack kernel
     double bb_lo[7] = { 0 }, bb_hi[7] = { 0 }; bool bb_ok = false;
+    uint64_t order_seq = 0;        // last draw that reads its sort index from this buffer (its binning kernel does, on the raster stream)
+    uint64_t data_seq = 0;         // last draw that reads its records from this buffer (the SoA repack / projection kernels do)
     bool alive = false;
 };
 
@@ -40,6 +43,7 @@ struct DrawArgs {
     bool quads = false;
     bool fb_was_clear = false;     // framebuffer state the composite of this draw must start from (kept for a re-run)
     int pre_idx = 0;               // which projected-record buffer the draw uses
+    uint64_t seq = 0;              // draw number (1, 2, ...): indexes the ring of binning-done events
 };
 
 thread_local std::string g_create_error;
@@ -51,6 +55,7 @@ struct gs4d_ctx {
     int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
     hipStream_t st = nullptr;          // stream in use (own_st unless the caller supplied one)
     hipStream_t own_st = nullptr;
+    bool single_stream = false;
     // Two streams.  `st` (the caller-visible one) carries the ORDER stage of a frame: SoA refresh, key generation, depth sort.
     // `rs` carries the RASTER stage: preprocess, tile binning, tile sort, composite, read-back.  The raster stage of frame f and the
     // order stage of frame f+1 touch disjoint data (the draw keeps a private copy of the sort index it was given), so consecutive
@@ -61,10 +66,13 @@ struct gs4d_ctx {
     hipEvent_t ev_raster_done[2] = { nullptr, nullptr };   // rs: the composite that read proj[i] has finished -> ps waits before overwriting proj[i]
     hipEvent_t ev_soa = nullptr;          // st: SoA shadow rebuilt                          -> rs waits before preprocess
     hipEvent_t ev_order_ready = nullptr;  // st: everything queued before the draw call      -> rs waits before binning reads the sort index
-    hipEvent_t ev_emit_done = nullptr;    // rs: binning has read (and copied) the sort index -> st waits before overwriting that buffer
+    static constexpr int EMIT_RING = 8;
+    hipEvent_t ev_emit[EMIT_RING] = { nullptr };   // rs: draw `seq`'s binning has read (and copied) the sort index -> st waits on slot seq % 8 before overwriting that buffer
+    uint64_t draw_seq = 0;                // draws enqueued so far
+    uint64_t done_seq = 0;                // draws known to have finished entirely (set by sync_all)
+    uint64_t emit_known = 0;              // draws whose binning kernel is known to have finished (set by resolve_pending)
     hipEvent_t ev_readback = nullptr;     // rs: device-side read-back enqueued               -> st waits so the caller's stream sees it
     uint32_t* order_copy = nullptr; size_t order_cap = 0;   // private copy of the last draw's sort index (for a re-run after overflow)
-    gs4d_buf last_order = 0;              // buffer the in-flight draw read its sort index from
     std::string err;
     std::vector<Buffer> bufs;          // index = name; bufs[0] unused
     gs4d_buf slots[8] = { 0 };
@@ -120,12 +128,14 @@ int sync_all(gs4d_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->st));
     HIPCHK(c, hipStreamSynchronize(c->ps));
     HIPCHK(c, hipStreamSynchronize(c->rs));
+    c->done_seq = c->draw_seq;
     return GS4D_OK;
 }
 
 int ensure_soa(gs4d_ctx* c, Buffer& b) {
     const size_t n = b.bytes / 96;
     if (b.soa && b.soa_n == n && b.soa_version == b.version) return GS4D_OK;
+    if (b.data_seq > c->done_seq) { int rc = sync_all(c); if (rc) return rc; }      // a running draw still projects from the old shadow
     if (!b.soa || b.soa_n != n) {
         if (b.soa) { int rc = sync_all(c); if (rc) return rc; (void)hipFree(b.soa); b.soa = nullptr; }
         if (n) HIPCHK(c, hipMalloc(&b.soa, n * 96));
@@ -160,7 +170,7 @@ int ensure_pairs(gs4d_ctx* c, size_t cap) {
 }
 
 // Enqueue binning -> tile sort -> ranges -> composite on the raster stream for projected records already in c->proj.
-int enqueue_raster(gs4d_ctx* c, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, int pre_idx) {
+int enqueue_raster(gs4d_ctx* c, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, int pre_idx, uint64_t seq) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
@@ -172,7 +182,7 @@ int enqueue_raster(gs4d_ctx* c, const uint32_t* order, uint32_t* order_copy, siz
         HIPCHK(c, launch_binning(c->rs, c->bin, c->rects2[pre_idx], order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err,
                                  ph, tile_passes, c->host_total_dev));
     }
-    HIPCHK(c, hipEventRecord(c->ev_emit_done, c->rs));     // the last binning workgroup wrote the total straight into pinned host memory
+    HIPCHK(c, hipEventRecord(c->ev_emit[seq % gs4d_ctx::EMIT_RING], c->rs));     // the last binning workgroup wrote the total straight into pinned host memory
     {
         StageTimer t(c, GS4D_T_PAIRSORT, c->rs);
         HIPCHK(c, radix_sort_pairs(c->rs, c->pair_sort, c->pair_keys, c->pair_vals, c->pair_cap, c->bin.total, tile_bits, true));
@@ -248,7 +258,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
     if (c->pair_cap < want) { int rc = ensure_pairs(c, want); if (rc) return rc; }
-    return enqueue_raster(c, order, order_copy, a.instances, npre, premult, a.fb_was_clear, a.pre_idx);
+    return enqueue_raster(c, order, order_copy, a.instances, npre, premult, a.fb_was_clear, a.pre_idx, a.seq);
 }
 
 // A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
@@ -256,8 +266,9 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
 // re-run with exact capacity (the projected records are still valid; inputs are unchanged by construction).
 int resolve_pending(gs4d_ctx* c) {
     while (c->pending) {
-        HIPCHK(c, hipEventSynchronize(c->ev_emit_done));     // the entry count is final once the binning kernel has run
+        HIPCHK(c, hipEventSynchronize(c->ev_emit[c->pending_args.seq % gs4d_ctx::EMIT_RING]));     // the entry count is final once the binning kernel has run
         c->pending = false;
+        if (c->emit_known < c->pending_args.seq) c->emit_known = c->pending_args.seq;
         if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "radix sort: a look-back spin timed out on the device (results of this frame are invalid)");
         const uint64_t total = (uint64_t)c->host_total[2] | ((uint64_t)c->host_total[3] << 32);
         if (!c->host_total[1]) { c->stat_entries = total; break; }
@@ -273,12 +284,25 @@ int resolve_pending(gs4d_ctx* c) {
     return GS4D_OK;
 }
 
-int touches_pending(gs4d_ctx* c, gs4d_buf b) { return c->pending && (c->pending_args.data == b || c->pending_args.order == b); }
+// Is a draw that reads buffer `B` possibly still running?  (The host may be many frames ahead of the device.)
+bool in_flight(gs4d_ctx* c, const Buffer& B) { return B.order_seq > c->done_seq || B.data_seq > c->done_seq; }
+
+// The host is about to write (or free) `B`: wait for every draw that reads it.
+int host_write_hazard(gs4d_ctx* c, const Buffer& B) {
+    if (!in_flight(c, B)) return GS4D_OK;
+    int rc = resolve_pending(c); if (rc) return rc;
+    return sync_all(c);
+}
 
 // The order stage is about to overwrite `b`: if the in-flight draw reads its sort index from it, wait (on the device) until the
 // binning kernel has consumed and copied it.  No host synchronisation.
 int order_write_hazard(gs4d_ctx* c, gs4d_buf b) {
-    if (b != 0 && b == c->last_order) HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_emit_done, 0));
+    Buffer* B = getbuf(c, b);
+    if (!B) return GS4D_OK;
+    if (B->data_seq > c->done_seq) return host_write_hazard(c, *B);          // overwriting the records of a running draw: rare, settle on the host
+    const uint64_t known = c->done_seq > c->emit_known ? c->done_seq : c->emit_known;
+    // ring slot seq % 8 holds the record of draw `seq` or of a later one: waiting for it is sufficient either way
+    if (B->order_seq > known) HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_emit[B->order_seq % gs4d_ctx::EMIT_RING], 0));
     return GS4D_OK;
 }
 
@@ -321,9 +345,13 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
     if ((e = hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
     c->st = c->own_st;
-    if ((e = hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
-    if ((e = hipStreamCreateWithFlags(&c->ps, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
-    for (hipEvent_t* ev : { &c->ev_soa, &c->ev_order_ready, &c->ev_emit_done, &c->ev_readback, &c->ev_pre_done, &c->ev_raster_done[0], &c->ev_raster_done[1] }) {
+    c->single_stream = getenv("GS4D_STREAMS") && atoi(getenv("GS4D_STREAMS")) == 1;     // tuning knob (experiments only): every stage on one stream
+    if (c->single_stream) { c->rs = c->ps = c->own_st; }
+    else {
+        if ((e = hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
+        if ((e = hipStreamCreateWithFlags(&c->ps, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
+    }
+    for (hipEvent_t* ev : { &c->ev_soa, &c->ev_order_ready, &c->ev_emit[0], &c->ev_emit[1], &c->ev_emit[2], &c->ev_emit[3], &c->ev_emit[4], &c->ev_emit[5], &c->ev_emit[6], &c->ev_emit[7], &c->ev_readback, &c->ev_pre_done, &c->ev_raster_done[0], &c->ev_raster_done[1] }) {
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
         if ((e = hipEventRecord(*ev, c->st)) != hipSuccess) return bail(hipfail(c, e, "hipEventRecord"));      // "already happened"
     }
@@ -355,9 +383,9 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (c->host_total) (void)hipHostFree(c->host_total);
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t ev : { c->ev_soa, c->ev_order_ready, c->ev_emit_done, c->ev_readback, c->ev_pre_done, c->ev_raster_done[0], c->ev_raster_done[1] }) if (ev) (void)hipEventDestroy(ev);
-    if (c->rs) (void)hipStreamDestroy(c->rs);
-    if (c->ps) (void)hipStreamDestroy(c->ps);
+    for (hipEvent_t ev : { c->ev_soa, c->ev_order_ready, c->ev_emit[0], c->ev_emit[1], c->ev_emit[2], c->ev_emit[3], c->ev_emit[4], c->ev_emit[5], c->ev_emit[6], c->ev_emit[7], c->ev_readback, c->ev_pre_done, c->ev_raster_done[0], c->ev_raster_done[1] }) if (ev) (void)hipEventDestroy(ev);
+    if (c->rs && !c->single_stream) (void)hipStreamDestroy(c->rs);
+    if (c->ps && !c->single_stream) (void)hipStreamDestroy(c->ps);
     if (c->own_st) (void)hipStreamDestroy(c->own_st);
     delete c;
 }
@@ -396,7 +424,7 @@ int gs4d_buffer_subdata(gs4d_ctx* c, gs4d_buf b, size_t offset, const void* data
     if (offset > B->bytes || bytes > B->bytes - offset) return fail(c, GS4D_E_INVALID, "buffer_subdata: range outside the buffer");   // GL_INVALID_VALUE
     if (!bytes) return GS4D_OK;
     if (!data) return fail(c, GS4D_E_INVALID, "buffer_subdata: data == NULL");
-    if (touches_pending(c, b) || b == c->last_order) { int rc = resolve_pending(c); if (rc) return rc; rc = sync_all(c); if (rc) return rc; }
+    { int rc = host_write_hazard(c, *B); if (rc) return rc; }
     // the caller keeps ownership of `data` and may reuse it on return (glBufferSubData semantics): copy synchronously
     HIPCHK(c, hipMemcpyAsync((char*)B->d + offset, data, bytes, hipMemcpyHostToDevice, c->st));
     HIPCHK(c, hipStreamSynchronize(c->st));
@@ -427,7 +455,6 @@ int gs4d_buffer_destroy(gs4d_ctx* c, gs4d_buf b) {
     if (B->bbox_dev) (void)hipFree(B->bbox_dev);
     *B = Buffer();
     for (auto& s : c->slots) if (s == b) s = 0;     // a deleted buffer is unbound
-    if (c->last_order == b) c->last_order = 0;
     if (c->kg_buf == b) c->kg_buf = 0;
     return GS4D_OK;
 }
@@ -564,11 +591,12 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     a.data_version = d ? d->version : 0; a.order_version = o ? o->version : 0;
     a.fb_was_clear = c->fb_is_clear;
     a.pre_idx = c->pre_idx ^ 1;
+    a.seq = c->draw_seq + 1;
     const size_t before = c->proj_n;
     c->proj_n = 0;
     rc = run_draw(c, a, true);
     if (rc) { c->proj_n = before; return rc; }
-    if (c->proj_n) { c->pending = true; c->pending_args = a; c->fb_is_clear = false; c->last_order = a.order; c->pre_idx = a.pre_idx; }   // proj_n != 0 <=> raster work was enqueued
+    if (c->proj_n) { c->pending = true; c->pending_args = a; c->fb_is_clear = false; c->pre_idx = a.pre_idx; c->draw_seq = a.seq; if (d) d->data_seq = a.seq; if (o && a.mode == GS4D_MODE_4D_SORTED && !a.quads) o->order_seq = a.seq; }   // proj_n != 0 <=> raster work was enqueued
     if (c->profiling && c->prof_frame < gs4d_ctx::PROF_FRAMES) c->prof_frame++;
     return GS4D_OK;
 }
@@ -641,6 +669,7 @@ int gs4d_set_stream(gs4d_ctx* c, void* hip_stream) {
     int rc = resolve_pending(c); if (rc) return rc;
     rc = sync_all(c); if (rc) return rc;             // everything queued so far completes before work moves to the other stream
     c->st = hip_stream ? (hipStream_t)hip_stream : c->own_st;
+    if (c->single_stream) c->rs = c->ps = c->st;
     return GS4D_OK;
 }
 
@@ -677,6 +706,30 @@ int gs4d_get_timings(gs4d_ctx* c, float ms[GS4D_T_COUNT]) {
     }
     c->prof_frame = 0;
     std::fill(c->ran.begin(), c->ran.end(), 0);
+    return GS4D_OK;
+}
+
+int gs4d_get_timeline(gs4d_ctx* c, float* ms, int max_frames, int* frames_out) {
+    if (!c || !ms || !frames_out || max_frames < 0) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    int rc = resolve_pending(c); if (rc) return rc;
+    rc = sync_all(c); if (rc) return rc;
+    const int frames = std::min(std::min(max_frames, c->prof_frame), (int)gs4d_ctx::PROF_FRAMES);
+    *frames_out = frames;
+    if (c->ran.empty() || frames == 0) { *frames_out = 0; return GS4D_OK; }
+    int base = -1;                                   // first stage of frame 0 that ran: time zero
+    for (int i = 0; i < GS4D_T_COUNT && base < 0; ++i) if (c->ran[i]) base = i;
+    if (base < 0) { *frames_out = 0; return GS4D_OK; }
+    for (int f = 0; f < frames; ++f)
+        for (int i = 0; i < GS4D_T_COUNT; ++i) {
+            const int slot = f * GS4D_T_COUNT + i;
+            float t0 = -1.0f, t1 = -1.0f;
+            if (c->ran[slot]) {
+                if (hipEventElapsedTime(&t0, c->ev0[base], c->ev0[slot]) != hipSuccess) t0 = -1.0f;
+                if (hipEventElapsedTime(&t1, c->ev0[base], c->ev1[slot]) != hipSuccess) t1 = -1.0f;
+            }
+            ms[(size_t)slot * 2] = t0; ms[(size_t)slot * 2 + 1] = t1;
+        }
     return GS4D_OK;
 }
 

@@ -30,6 +30,7 @@ struct SortScratch {
     uint32_t* hist = nullptr; size_t hist_cap = 0;                          // two [OS_REPL][4][256] digit-histogram slots (alternating), then the look-back words
     int flip = 0;
     bool hist_pending = false;         // the current slot holds a histogram accumulated by a producer kernel, not yet consumed by a sort
+    int acc_flip = 0;                  // which accumulator set the next launch uses (the other one it zeroes)
     int hist_bits = 32;                // host-proven width of (key - hist_bias): passes above it are not even launched
     uint32_t hist_bias = 0;            // ... of (key - hist_bias): a lower bound of all keys, which makes the high digits constant (and their passes skipped)
     uint32_t epoch = 0;                // tag of the look-back words of the latest pass launch

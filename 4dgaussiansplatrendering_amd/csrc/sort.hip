@@ -94,11 +94,8 @@ hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, 
 // frame as failed instead of hanging the GPU or returning wrong data.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t OS_GROUP = 32;         // tiles per look-back group
+constexpr uint32_t OS_SUPER = 32;         // groups per super-group
 typedef unsigned long long u64;
-constexpr u64 OS_AGG = 1ull, OS_INCL = 2ull;
-
-__device__ __forceinline__ u64 os_word(uint32_t epoch, u64 flag, uint32_t value) { return ((u64)epoch << 34) | (flag << 32) | (u64)value; }
-__device__ __forceinline__ uint32_t os_flag(u64 w, uint32_t epoch) { return (uint32_t)(w >> 34) == epoch ? (uint32_t)(w >> 32) & 3u : 0u; }
 
 struct OsBufs { uint32_t* k[3]; uint32_t* v[3]; };      // [0] caller's buffers, [1],[2] scratch
 
@@ -158,59 +155,109 @@ __device__ __forceinline__ bool os_schedule(uint32_t* s_live /* [4] 0/1, may be 
 __device__ __forceinline__ uint32_t os_tword(uint32_t epoch, uint32_t count) { return ((epoch & 0x3FFFFu) << 14) | count; }
 __device__ __forceinline__ bool os_tpublished(uint32_t w, uint32_t epoch) { return (w >> 14) == (epoch & 0x3FFFFu); }
 
-// Sum of the tile-level counts of rows hi, hi-1, ..., lo (all must be published; at most LB rows) for digit `tid`.
+// ---- look-back reads ----
+// A round of agent-scope loads costs 1.5-3 us on a busy device, so the look-back is built to need ONE: the words of the group's earlier
+// tiles and the accumulators of the super-group's earlier groups are all requested before any of them is examined.
+// Polling discipline when something is still missing: spin on the FIRST missing word alone (one load per thread and round, with a
+// sleep), then read the rest again.  Re-reading everything every round is a polling storm — a few hundred tiles asking for tens of
+// TB/s — and the stores everybody is waiting for queue up behind it.
+
+// rows hi-k0 .. hi-(rows-1) of the tile words are outstanding and row hi-k0 is known to be missing
 template <int LB>
-__device__ __forceinline__ uint32_t os_sum_tiles(const uint32_t* st, int32_t hi, int32_t lo, uint32_t tid, uint32_t epoch, uint32_t* err) {
-    uint32_t sum = 0, spins = 0;
-    int k0 = 0;
+__device__ __forceinline__ uint32_t os_tiles_finish(const uint32_t* st, int32_t hi, int rows, int k0, uint32_t sum, uint32_t tid, uint32_t epoch, uint32_t* err) {
+    uint32_t spins = 0;
     while (true) {
+        while (true) {
+            __builtin_amdgcn_s_sleep(8);
+            const uint32_t w = __hip_atomic_load(st + (size_t)(hi - k0) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (os_tpublished(w, epoch)) { sum += w & 0x3FFFu; break; }
+            if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return sum; }
+        }
+        if (++k0 >= rows) return sum;
         uint32_t sv[LB];
 #pragma unroll
-        for (int k = 0; k < LB; ++k) {
-            const int32_t tt = hi - k;
-            sv[k] = (k >= k0 && tt >= lo) ? __hip_atomic_load(st + (size_t)tt * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        }
-        bool retry = false;
+        for (int k = 0; k < LB; ++k) sv[k] = (k >= k0 && k < rows) ? __hip_atomic_load(st + (size_t)(hi - k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        bool missing = false;
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
-            if (retry || k < k0 || hi - k < lo) continue;
-            if (!os_tpublished(sv[k], epoch)) { k0 = k; retry = true; continue; }
+            if (missing || k < k0 || k >= rows) continue;
+            if (!os_tpublished(sv[k], epoch)) { k0 = k; missing = true; continue; }
             sum += sv[k] & 0x3FFFu;
         }
-        if (!retry) return sum;
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return sum; }
+        if (!missing) return sum;
     }
 }
 
-// Descending look-back over group words hi..0 for digit `tid`: adds values until a word flagged INCL (or the start).
+// accumulator rows t+k0 .. t+rows-1 are outstanding and row t+k0 is known to be incomplete (complete = `expect` arrivals)
 template <int LB>
-__device__ __forceinline__ uint32_t os_sum_groups(const u64* st, int32_t hi, uint32_t tid, uint32_t epoch, uint32_t* err) {
-    uint32_t sum = 0, spins = 0;
-    for (int32_t t = hi; t >= 0; t -= LB) {
-        int k0 = 0;
+__device__ __forceinline__ uint32_t os_acc_finish(const u64* acc, uint32_t t, int rows, int k0, uint32_t sum, uint32_t expect, uint32_t tid, uint32_t* err) {
+    uint32_t spins = 0;
+    while (true) {
         while (true) {
-            u64 sv[LB];
-#pragma unroll
-            for (int k = 0; k < LB; ++k) {
-                const int32_t tt = t - k;
-                sv[k] = (k >= k0 && tt >= 0) ? __hip_atomic_load(st + (size_t)tt * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-            }
-            bool retry = false;
-#pragma unroll
-            for (int k = 0; k < LB; ++k) {
-                if (retry || k < k0 || t - k < 0) continue;
-                const uint32_t f = os_flag(sv[k], epoch);
-                if (f == 0u) { k0 = k; retry = true; continue; }
-                sum += (uint32_t)sv[k];
-                if (f == 2u) return sum;
-            }
-            if (!retry) break;
-            __builtin_amdgcn_s_sleep(4);
+            __builtin_amdgcn_s_sleep(8);
+            const u64 w = __hip_atomic_load(acc + (size_t)(t + k0) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint32_t)(w >> 32) == expect) { sum += (uint32_t)w; break; }
             if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return sum; }
         }
+        if (++k0 >= rows) return sum;
+        u64 sv[LB];
+#pragma unroll
+        for (int k = 0; k < LB; ++k) sv[k] = (k >= k0 && k < rows) ? __hip_atomic_load(acc + (size_t)(t + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        bool missing = false;
+#pragma unroll
+        for (int k = 0; k < LB; ++k) {
+            if (missing || k < k0 || k >= rows) continue;
+            if ((uint32_t)(sv[k] >> 32) != expect) { k0 = k; missing = true; continue; }
+            sum += (uint32_t)sv[k];
+        }
+        if (!missing) return sum;
     }
-    return sum;
+}
+
+// Exclusive prefix of tile `tile` for digit `tid`: earlier tiles of its group + earlier groups of its super-group + earlier super-groups.
+__device__ __forceinline__ uint32_t os_lookback(const uint32_t* st, const u64* acc, uint32_t acc_groups, uint32_t tile, uint32_t tid, uint32_t epoch, uint32_t* err) {
+    const uint32_t grp = tile / OS_GROUP, sup = grp / OS_SUPER;
+    const int rows_t = (int)(tile - grp * OS_GROUP), rows_g = (int)(grp - sup * OS_SUPER);
+    const int32_t hi = (int32_t)tile - 1;
+    const uint32_t g0 = sup * OS_SUPER;
+    uint32_t tv[OS_GROUP]; u64 gv[OS_SUPER];
+#pragma unroll
+    for (int k = 0; k < (int)OS_GROUP; ++k) tv[k] = k < rows_t ? __hip_atomic_load(st + (size_t)(hi - k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+    for (int k = 0; k < (int)OS_SUPER; ++k) gv[k] = k < rows_g ? __hip_atomic_load(acc + (size_t)(g0 + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    uint32_t sum_t = 0, sum_g = 0, sum_s = 0;
+    int miss_t = -1, miss_g = -1;
+#pragma unroll
+    for (int k = 0; k < (int)OS_GROUP; ++k) {
+        if (miss_t >= 0 || k >= rows_t) continue;
+        if (!os_tpublished(tv[k], epoch)) { miss_t = k; continue; }
+        sum_t += tv[k] & 0x3FFFu;
+    }
+#pragma unroll
+    for (int k = 0; k < (int)OS_SUPER; ++k) {
+        if (miss_g >= 0 || k >= rows_g) continue;
+        if ((uint32_t)(gv[k] >> 32) != OS_GROUP) { miss_g = k; continue; }
+        sum_g += (uint32_t)gv[k];
+    }
+    // earlier super-groups (sorts of more than 1024 tiles only), 16 at a time
+    const u64* sacc = acc + (size_t)acc_groups * 256u;
+    for (uint32_t t = 0; t < sup; t += 16u) {
+        const int rows = (int)min(16u, sup - t);
+        u64 sv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sv[k] = k < rows ? __hip_atomic_load(sacc + (size_t)(t + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        int miss = -1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (miss >= 0 || k >= rows) continue;
+            if ((uint32_t)(sv[k] >> 32) != OS_GROUP * OS_SUPER) { miss = k; continue; }
+            sum_s += (uint32_t)sv[k];
+        }
+        if (miss >= 0) sum_s = os_acc_finish<16>(sacc, t, rows, miss, sum_s, OS_GROUP * OS_SUPER, tid, err);
+    }
+    if (miss_t >= 0) sum_t = os_tiles_finish<(int)OS_GROUP>(st, hi, rows_t, miss_t, sum_t, tid, epoch, err);
+    if (miss_g >= 0) sum_g = os_acc_finish<(int)OS_SUPER>(acc, g0, rows_g, miss_g, sum_g, OS_GROUP, tid, err);
+    return sum_t + sum_g + sum_s;
 }
 
 // exclusive scan of one value per digit (threads 0..255 carry a value, all THREADS threads take part in the barriers)
@@ -230,7 +277,8 @@ __device__ __forceinline__ uint32_t digit_excl_scan(uint32_t v, uint32_t* tmp /*
 template <int THREADS, int ITEMS, bool ATOMIC_RANK>
 __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
                                                      const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
-                                                     uint32_t* status /* [tiles][256] */, u64* gstatus /* [groups][256] */, uint32_t epoch, uint32_t* err,
+                                                     uint32_t* status /* [tiles][256] */, u64* acc /* [acc_groups + supers][256], zero at launch */, u64* acc_next /* zeroed here */, uint32_t acc_groups, uint32_t acc_words,
+                                                     uint32_t epoch, uint32_t* err,
                                                      uint32_t* ticket, uint32_t ticket_base, uint32_t bias, u64* stamps /* tuning aid, may be null */) {
     constexpr uint32_t TILE_KEYS = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
@@ -249,27 +297,30 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     // Tile ids are handed out by ticket, in the order workgroups START: a tile only ever waits for tiles that are already running.
     // (With blockIdx as the tile id, two chained-scan kernels running side by side on different streams can dead-lock each other:
     // workgroups are dispatched per XCD, so each kernel's late tiles can fill the XCD the other kernel's early tiles need.)
+    // The ticket's round trip overlaps the histogram loads below, which do not depend on the tile.
     if (tid == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint32_t ntiles = (n + TILE_KEYS - 1u) / TILE_KEYS;
-    if (pass == 0 && tile == 0) { for (uint32_t q = tid; q < OS_SLOT_WORDS; q += THREADS) ghist_other[q] = 0u; }   // the histogram slot of the NEXT sort
-    if (tile >= ntiles) return;                                   // uniform
-    if (stamps && tid == 0) stamps[tile * 8 + 0] = wall_clock64();
-    const int shift = 8 * pass;
     if (tid < OS_MAX_PASSES) s_live[tid] = 1u;
     for (uint32_t q = tid; q < WAVES * 256u; q += THREADS) (&wcnt[0][0])[q] = 0u;
-    __syncthreads();
-    uint32_t tot = 0;
+    uint32_t tot = 0, dead = 0;
     if (tid < 256u) {
         for (int q = 0; q < passes; ++q) {
             uint32_t g = 0;
 #pragma unroll
             for (int r = 0; r < OS_REPL; ++r) g += ghist[(r * OS_MAX_PASSES + q) * 256 + tid];
             if (q == pass) tot = g;
-            if (g == n) s_live[q] = 0u;                           // one digit holds every key
+            if (g == n) dead |= 1u << q;                          // one digit holds every key
         }
     }
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t ntiles = (n + TILE_KEYS - 1u) / TILE_KEYS;
+    // housekeeping for the NEXT launch of this sorter: its group accumulators (every workgroup a slice), its histogram slot
+    for (uint32_t q = tile * THREADS + tid; q < acc_words; q += gridDim.x * THREADS) acc_next[q] = 0ull;
+    if (pass == 0 && tile == 0) { for (uint32_t q = tid; q < OS_SLOT_WORDS; q += THREADS) ghist_other[q] = 0u; }
+    if (tile >= ntiles) return;                                   // uniform
+    if (stamps && tid == 0) stamps[tile * 8 + 0] = wall_clock64();
+    const int shift = 8 * pass;
+    for (int q = 0; q < passes; ++q) if ((dead >> q) & 1u) s_live[q] = 0u;
     __syncthreads();
     int src, dst;
     if (!os_schedule(s_live, passes, pass, src, dst)) return;    // uniform: this pass is an identity
@@ -326,12 +377,15 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     __syncthreads();
     // thread d: counts per wave -> offsets inside the tile's digit-d run; tile count of digit d; publish it at once
     uint32_t cnt = 0;
-    const uint32_t grp = tile / OS_GROUP;
-    const bool last_in_group = (tile % OS_GROUP) == OS_GROUP - 1u;
+    const uint32_t grp = tile / OS_GROUP, sup = grp / OS_SUPER;
+    const uint32_t ngroups = (ntiles + OS_GROUP - 1u) / OS_GROUP, nsuper = (ngroups + OS_SUPER - 1u) / OS_SUPER;
     if (tid < 256u) {
 #pragma unroll
         for (int k = 0; k < WAVES; ++k) { const uint32_t t = wcnt[k][tid]; wcnt[k][tid] = cnt; cnt += t; }
         __hip_atomic_store(status + (size_t)tile * 256u + tid, os_tword(epoch, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // {arrivals:32, sum:32} accumulators of the group and of the super-group (only those a later tile will read)
+        if (grp + 1u < ngroups) (void)__hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1ull << 32) | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sup + 1u < nsuper) (void)__hip_atomic_fetch_add(acc + (size_t)(acc_groups + sup) * 256u + tid, (1ull << 32) | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (stamps && tid == 0) stamps[tile * 8 + 2] = wall_clock64();
     // local run starts, then the reorder inside LDS — none of it needs the other tiles, so it overlaps their publishing
@@ -348,13 +402,10 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         }
     }
     if (stamps && tid == 0) stamps[tile * 8 + 3] = wall_clock64();
-    // look back: the tiles of this group before this one, then the groups before this group
+    // look back, one memory round trip: the tiles of this group before this one (their words), the groups of this super-group
+    // before this group and the super-groups before this one (their accumulators, complete when every member has arrived)
     if (tid < 256u) {
-        uint32_t prefix = 0;
-        if (tile > grp * OS_GROUP) prefix = os_sum_tiles<(int)OS_GROUP>(status, (int32_t)tile - 1, (int32_t)(grp * OS_GROUP), tid, epoch, err);
-        if (last_in_group && grp > 0) __hip_atomic_store(gstatus + (size_t)grp * 256u + tid, os_word(epoch, OS_AGG, prefix + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (grp > 0) prefix += os_sum_groups<16>(gstatus, (int32_t)grp - 1, tid, epoch, err);
-        if (last_in_group) __hip_atomic_store(gstatus + (size_t)grp * 256u + tid, os_word(epoch, OS_INCL, prefix + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t prefix = os_lookback(status, acc, acc_groups, tile, tid, epoch, err);
         gpos[tid] = digit_base + prefix;
     }
     __syncthreads();
@@ -425,8 +476,9 @@ hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n) {
         s.cap = n;
     }
     // control block: two [OS_REPL][4][256] histogram slots (alternating), then the 64-bit look-back words [tiles + groups][256]
-    const size_t tiles = (n + 1023) / 1024;          // smallest tile = 1024 keys
-    const size_t words = 2 * OS_SLOT_WORDS + (tiles + 2 * (tiles / OS_GROUP + 2)) * 256;
+    const size_t tiles = (s.cap + 1023) / 1024;      // smallest tile = 1024 keys; sized for the largest sort seen (the layout depends on it)
+    const size_t groups = tiles / OS_GROUP + 2, supers = groups / OS_SUPER + 2;
+    const size_t words = 2 * OS_SLOT_WORDS + (tiles + 2 + 2 * 2 * (groups + supers)) * 256;       // tile words (u32), two accumulator sets (u64)
     if (s.hist_cap < words) {
         uint32_t* nh = nullptr;
         if ((e = hipMalloc(&nh, words * 4)) != hipSuccess) return e;
@@ -481,7 +533,10 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     u64* stamps = nullptr;
     if (stampf && hipMalloc(&stamps, (size_t)tiles * 64) != hipSuccess) stamps = nullptr;
     uint32_t* status = s.hist + 2 * OS_SLOT_WORDS;
-    u64* gstatus = reinterpret_cast<u64*>(status + (((size_t)tiles * 256 + 1) & ~(size_t)1));
+    // accumulator sets sit behind the tile words of the LARGEST sort this scratch was sized for (so they never move between launches)
+    const size_t cap_tiles = (s.cap + 1023) / 1024, cap_groups = cap_tiles / OS_GROUP + 2, cap_supers = cap_groups / OS_SUPER + 2;
+    const size_t acc_words = (cap_groups + cap_supers) * 256;
+    u64* acc_base = reinterpret_cast<u64*>(status + (cap_tiles + 2) * 256);
     OsBufs b;
     b.k[0] = keys; b.v[0] = vals;
     b.k[1] = s.keys2; b.v[1] = s.vals2;
@@ -492,9 +547,11 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
             if ((e = hipMemsetAsync(status, 0, (s.hist_cap - 2 * OS_SLOT_WORDS) * 4, st)) != hipSuccess) return e;
             ++s.epoch;
         }
-        k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(tiles), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, gstatus, s.epoch & 0x3FFFFFFFu,
+        k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(tiles), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, acc_base + (s.acc_flip ? acc_words : 0), acc_base + (s.acc_flip ? 0 : acc_words), (uint32_t)cap_groups, (uint32_t)acc_words,
+                                                                         s.epoch & 0x3FFFFFFFu,
                                                                          s.err ? s.err : s.totals, s.totals + 64, s.ticket_base, bias, (stampf && p == stamp_pass) ? stamps : nullptr);
         s.ticket_base += tiles;               // every workgroup of the launch draws exactly one ticket
+        s.acc_flip ^= 1;
     }
     if (stampf && stamps) {   // tuning aid: dump per-tile wall-clock stamps (100 MHz) of one pass
         (void)hipStreamSynchronize(st);

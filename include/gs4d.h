@@ -114,6 +114,9 @@ GS4D_API int gs4d_finish(gs4d_ctx* ctx);                                        
 /* ---- measurement / test hooks ---- */
 GS4D_API int gs4d_set_profiling(gs4d_ctx* ctx, int stage_mask);                   /* bit (1 << GS4D_T_x) times stage x; 0 = off, 0x3F = every stage; each timed stage costs two event records per frame */
 GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);             /* blocking; -1.0f for stages that did not run */
+/* Start and end of every timed stage of the frames recorded so far (at most 128), in ms since the first timed stage of frame 0:
+ * ms[frame][stage][2].  Shows how the three streams overlap.  Blocking; does not restart the ring (gs4d_get_timings does). */
+GS4D_API int gs4d_get_timeline(gs4d_ctx* ctx, float* ms, int max_frames, int* frames);
 GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[4]);                    /* [0] tile-list entries of the last draw, [1] capacity, [2] re-runs after overflow, [3] tiles */
 /* Projected records of the last draw, 16 floats per record in record order:
  * cx, cy, a0x, a0y, a1x, a1y, alpha, r, g, b, tile-rect (2 words, bit patterns), hx, hy, valid(1/0), 0 */
