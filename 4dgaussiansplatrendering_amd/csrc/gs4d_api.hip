@@ -6,11 +6,17 @@
 //   Shader::Bind/SetUniform1f/SetUniformMat4f               4DSplatRendering/Shader.cpp:171-174, 206-209
 //   radix_sort::sorter::sort                                Dependencies/GPU_RADIX_SORT/radix_sort.hpp:258-392
 //   Renderer::Clear / Renderer::Draw                        4DSplatRendering/Renderer.cpp:20-39
-// One HIP stream per context; API calls enqueue work in order and return; only read-back/finish calls block, plus the
-// validation of a draw's tile-list capacity, which is deferred to the next call that could observe it (see resolve_pending).
+//
+// Execution model: FRAME LANES.  A context owns a few lanes (2 by default, GS4D_LANES=1..4); a lane is one HIP stream with its own framebuffer,
+// projected records, tile lists and sort scratch.  Every call of one frame (key generation, depth sort, draw) is queued on the
+// current lane, in order — no events inside a frame.  The first frame-starting call (clear, keygen, sort) after a draw moves to the
+// next lane, so whole frames overlap on the device: the latency-bound kernels of one frame (the radix sort's chained scans) fill the
+// gaps of the bandwidth-bound kernels of its neighbours.  Lanes only meet through buffer objects and framebuffers; each of those
+// remembers which lane wrote it last and which lanes read it since, and a lane about to touch it waits on the other lane's event —
+// on the device, never on the host.  Only read-back/finish calls block, plus the validation of a draw's tile-list capacity, which
+// is deferred to the next call that could observe the draw (see resolve_pending).
 #include "gs4d_internal.h"
 #include <cstdio>
-#include <chrono>
 #include <cstring>
 #include <new>
 #include <algorithm>
@@ -20,17 +26,23 @@ using namespace gs4d;
 
 namespace {
 
+constexpr int MAX_LANES = 4;
+
 struct Buffer {
     void* d = nullptr;
     size_t bytes = 0;
-    uint64_t version = 0;          // bumped by every write; SoA shadow and pending-draw tracking compare against it
+    uint64_t version = 0;          // bumped by every write; the SoA shadow and the keygen-histogram hand-off compare against it
     float4* soa = nullptr;         // lazily built SoA shadow of 96-B SplatData records
     size_t soa_n = 0;
     uint64_t soa_version = ~0ull;
     uint32_t* bbox_dev = nullptr;  // 16 words: bounding box of pos / mu_t / velocity, reduced by the repack kernel
     double bb_lo[7] = { 0 }, bb_hi[7] = { 0 }; bool bb_ok = false;
-    uint64_t order_seq = 0;        // last draw that reads its sort index from this buffer (its binning kernel does, on the raster stream)
-    uint64_t data_seq = 0;         // last draw that reads its records from this buffer (the SoA repack / projection kernels do)
+    // cross-lane hazards
+    int wr_lane = -1;              // lane whose kernels wrote the buffer last (-1: the host did, synchronously)
+    unsigned ordered_mask = 0;     // lanes that have already ordered themselves after that write
+    unsigned rd_mask = 0;          // lanes whose DRAWS have read it since that write (their binning-done event covers the reads)
+    unsigned tail_mask = 0;        // lanes whose other kernels (key generation) have read it since that write (their tail event does)
+    uint64_t touch = 0;            // context op counter at the last device-side use (host writes compare it with the last full sync)
     bool alive = false;
 };
 
@@ -38,12 +50,31 @@ struct DrawArgs {
     int mode = 0;
     Uniforms u;
     gs4d_buf data = 0, order = 0;
-    uint64_t data_version = 0, order_version = 0;
     size_t instances = 0;
     bool quads = false;
     bool fb_was_clear = false;     // framebuffer state the composite of this draw must start from (kept for a re-run)
-    int pre_idx = 0;               // which projected-record buffer the draw uses
-    uint64_t seq = 0;              // draw number (1, 2, ...): indexes the ring of binning-done events
+    int lane = 0, fb = 0;          // where the draw ran
+};
+
+struct Framebuffer {
+    float4* mem = nullptr;
+    bool is_clear = true;          // content == clear colour, not yet materialised
+    int last_lane = -1;            // lane that touched it last
+};
+
+struct Lane {
+    hipStream_t s = nullptr;
+    hipEvent_t ev_emit = nullptr;      // the lane's latest binning kernel has finished (it read and copied the sort index; its entry count is final)
+    hipEvent_t ev_tail = nullptr;      // recorded when the lane is left: everything queued on it so far
+    bool drawn = false;                // the lane's current frame has a draw in it: the next frame-starting call moves on
+    float4* proj = nullptr; uint2* rects = nullptr; size_t proj_cap = 0, proj_n = 0;   // projected records (64 B) and their pixel rectangles
+    uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;
+    uint32_t* order_copy = nullptr; size_t order_cap = 0;   // private copy of the last draw's sort index (for a re-run after overflow)
+    SortScratch depth_sort, pair_sort;
+    BinScratch bin;
+    uint32_t* host_total = nullptr;     // pinned + mapped: [0..3] the binning total of the last draw, [4] the error word kernels raise
+    uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
+    gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
 };
 
 thread_local std::string g_create_error;
@@ -53,49 +84,24 @@ thread_local std::string g_create_error;
 struct gs4d_ctx {
     int device = 0;
     int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
-    hipStream_t st = nullptr;          // stream in use (own_st unless the caller supplied one)
-    hipStream_t own_st = nullptr;
-    bool single_stream = false;
-    // Two streams.  `st` (the caller-visible one) carries the ORDER stage of a frame: SoA refresh, key generation, depth sort.
-    // `rs` carries the RASTER stage: preprocess, tile binning, tile sort, composite, read-back.  The raster stage of frame f and the
-    // order stage of frame f+1 touch disjoint data (the draw keeps a private copy of the sort index it was given), so consecutive
-    // frames overlap on the GPU; the events below carry the few true dependencies.
-    hipStream_t rs = nullptr;
-    hipStream_t ps = nullptr;             // preprocess stream: the projection of frame f+1 runs beside both stages (double-buffered outputs)
-    hipEvent_t ev_pre_done = nullptr;     // ps: projected records written                  -> rs waits before binning
-    hipEvent_t ev_raster_done[2] = { nullptr, nullptr };   // rs: the composite that read proj[i] has finished -> ps waits before overwriting proj[i]
-    hipEvent_t ev_soa = nullptr;          // st: SoA shadow rebuilt                          -> rs waits before preprocess
-    hipEvent_t ev_order_ready = nullptr;  // st: everything queued before the draw call      -> rs waits before binning reads the sort index
-    static constexpr int EMIT_RING = 8;
-    hipEvent_t ev_emit[EMIT_RING] = { nullptr };   // rs: draw `seq`'s binning has read (and copied) the sort index -> st waits on slot seq % 8 before overwriting that buffer
-    uint64_t draw_seq = 0;                // draws enqueued so far
-    uint64_t done_seq = 0;                // draws known to have finished entirely (set by sync_all)
-    uint64_t emit_known = 0;              // draws whose binning kernel is known to have finished (set by resolve_pending)
-    hipEvent_t ev_readback = nullptr;     // rs: device-side read-back enqueued               -> st waits so the caller's stream sees it
-    uint32_t* order_copy = nullptr; size_t order_cap = 0;   // private copy of the last draw's sort index (for a re-run after overflow)
+    int nlanes = 2, cur = 0;
+    Lane lanes[MAX_LANES];
+    Framebuffer fbs[MAX_LANES];        // fbs[i] belongs to lane i; a clear makes the current lane's own framebuffer the current one
+    int cur_fb = 0;
+    hipStream_t user = nullptr;        // the caller's stream (gs4d_set_stream), or null
+    hipEvent_t ev_user = nullptr;      // user stream -> lane: what the caller queued before an API call
+    hipEvent_t ev_readback = nullptr;  // lane -> user stream: a device-side read-back
     std::string err;
     std::vector<Buffer> bufs;          // index = name; bufs[0] unused
     gs4d_buf slots[8] = { 0 };
     int mode = GS4D_MODE_4D_SORTED;
     Uniforms u;
     float clear[4] = { 0.0f, 0.0f, 0.0f, 0.0f };     // GL's initial clear colour; the app sets its own (Application.cpp:125)
-    float4* fb = nullptr;
-    bool fb_is_clear = true;           // framebuffer content == clear colour, not yet materialised
-    // per-draw scratch
-    float4* proj2[2] = { nullptr, nullptr }; size_t proj_cap = 0; size_t proj_n = 0;   // projected records, double-buffered across draws
-    uint2* rects2[2] = { nullptr, nullptr };   // compact pixel rectangles, one per projected record
-    int pre_idx = 0;                   // buffer the latest draw projected into
-    uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;
-    SortScratch depth_sort, pair_sort;
-    BinScratch bin;
-    uint32_t* host_total = nullptr;    // pinned + mapped: [0..3] the binning total of the last draw, [4] the error word kernels raise when a bounded spin times out
-    uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
-    uint32_t* dev_err = nullptr;       // = host_total_dev + 4
-    gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
-    bool pending = false;
+    bool atomic_rank = false;          // result of the LDS-atomic ordering self-test
+    uint64_t ops = 0, synced = 0;      // device-side uses so far / at the last sync of every lane
+    bool pending = false;              // the last draw's tile-list capacity has not been validated yet
     DrawArgs pending_args;
     uint64_t stat_entries = 0, stat_reruns = 0;
-    // profiling
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
     static constexpr int PROF_FRAMES = 128;
     unsigned profiling = 0;                    // bit s set: stage s is timed
@@ -114,42 +120,101 @@ int hipfail(gs4d_ctx* c, hipError_t e, const char* where) {
 }
 #define HIPCHK(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hipfail((c), e__, #call); } while (0)
 
+const char* const DEVICE_CHECK_MSG = "device-side check failed (a bounded look-back wait timed out, or a sort key fell outside its proven bounds): results are invalid";
+
 Buffer* getbuf(gs4d_ctx* c, gs4d_buf b) { return (b != 0 && b < c->bufs.size() && c->bufs[b].alive) ? &c->bufs[b] : nullptr; }
+Lane& lane(gs4d_ctx* c) { return c->lanes[c->cur]; }
 
 struct StageTimer {
     gs4d_ctx* c; int slot; hipStream_t s;
-    StageTimer(gs4d_ctx* c_, int id, hipStream_t stream = nullptr) : c(c_), slot(-1), s(stream ? stream : c_->st) {
+    StageTimer(gs4d_ctx* c_, int id) : c(c_), slot(-1), s(c_->lanes[c_->cur].s) {
         if (((c->profiling >> id) & 1u) && c->prof_frame < gs4d_ctx::PROF_FRAMES) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], s); }
     }
     ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(c->ev1[slot], s); c->ran[slot] = 1; } }
 };
 
 int sync_all(gs4d_ctx* c) {
-    HIPCHK(c, hipStreamSynchronize(c->st));
-    HIPCHK(c, hipStreamSynchronize(c->ps));
-    HIPCHK(c, hipStreamSynchronize(c->rs));
-    c->done_seq = c->draw_seq;
+    for (int i = 0; i < c->nlanes; ++i) HIPCHK(c, hipStreamSynchronize(c->lanes[i].s));
+    c->synced = c->ops;
+    return GS4D_OK;
+}
+
+bool device_error(gs4d_ctx* c) { for (int i = 0; i < c->nlanes; ++i) if (c->lanes[i].host_total[4]) return true; return false; }
+
+// The current frame is complete (it has a draw in it) and a new one starts: move to the next lane.
+int next_frame_if_drawn(gs4d_ctx* c) {
+    Lane& L = lane(c);
+    if (!L.drawn) return GS4D_OK;
+    HIPCHK(c, hipEventRecord(L.ev_tail, L.s));
+    L.drawn = false;
+    c->cur = (c->cur + 1) % c->nlanes;
+    lane(c).drawn = false;
+    return GS4D_OK;
+}
+
+// What the caller queued on its own stream before this API call happens before what the call queues.
+int after_user_stream(gs4d_ctx* c) {
+    if (!c->user) return GS4D_OK;
+    HIPCHK(c, hipEventRecord(c->ev_user, c->user));
+    HIPCHK(c, hipStreamWaitEvent(lane(c).s, c->ev_user, 0));
+    return GS4D_OK;
+}
+
+// The current lane is about to read (or overwrite) buffer B with a kernel: order it after the other lanes' kernels that wrote B
+// (or, for a write, still read it).  Device-side waits only.  A lane other than the current one has been left since it last touched
+// B, so its tail event (recorded on leaving) covers that use; a draw's reads are already covered by its binning-done event.
+int lane_access(gs4d_ctx* c, Buffer& B, bool write) {
+    Lane& L = lane(c);
+    const unsigned me = 1u << c->cur;
+    if (B.wr_lane >= 0 && B.wr_lane != c->cur && !(B.ordered_mask & me)) {
+        HIPCHK(c, hipStreamWaitEvent(L.s, c->lanes[B.wr_lane].ev_tail, 0));
+        B.ordered_mask |= me;
+    }
+    if (write) {
+        for (int r = 0; r < c->nlanes; ++r) {
+            if (r == c->cur) continue;
+            if ((B.tail_mask >> r) & 1u) HIPCHK(c, hipStreamWaitEvent(L.s, c->lanes[r].ev_tail, 0));
+            else if ((B.rd_mask >> r) & 1u) HIPCHK(c, hipStreamWaitEvent(L.s, c->lanes[r].ev_emit, 0));
+        }
+        B.rd_mask = 0; B.tail_mask = 0; B.wr_lane = c->cur; B.ordered_mask = me;
+    }
+    B.touch = ++c->ops;
+    return GS4D_OK;
+}
+
+// The host is about to write, read or free B: wait for every kernel that may still use it.
+int host_access(gs4d_ctx* c, Buffer& B);
+
+int ensure_pairs(gs4d_ctx* c, Lane& L, size_t cap) {
+    if (L.pair_cap >= cap) return GS4D_OK;
+    HIPCHK(c, hipStreamSynchronize(L.s));
+    if (L.pair_keys) (void)hipFree(L.pair_keys);
+    if (L.pair_vals) (void)hipFree(L.pair_vals);
+    L.pair_keys = L.pair_vals = nullptr; L.pair_cap = 0;
+    HIPCHK(c, hipMalloc(&L.pair_keys, cap * 4));
+    HIPCHK(c, hipMalloc(&L.pair_vals, cap * 4));
+    L.pair_cap = cap;
     return GS4D_OK;
 }
 
 int ensure_soa(gs4d_ctx* c, Buffer& b) {
     const size_t n = b.bytes / 96;
     if (b.soa && b.soa_n == n && b.soa_version == b.version) return GS4D_OK;
-    if (b.data_seq > c->done_seq) { int rc = sync_all(c); if (rc) return rc; }      // a running draw still projects from the old shadow
+    if (b.touch > c->synced) { int rc = sync_all(c); if (rc) return rc; }      // a running draw may still project from the old shadow
+    Lane& L = lane(c);
     if (!b.soa || b.soa_n != n) {
-        if (b.soa) { int rc = sync_all(c); if (rc) return rc; (void)hipFree(b.soa); b.soa = nullptr; }
+        if (b.soa) { (void)hipFree(b.soa); b.soa = nullptr; }
         if (n) HIPCHK(c, hipMalloc(&b.soa, n * 96));
         b.soa_n = n;
     }
     // bounding box of everything the sort key depends on (upload-time work: one small read-back per refresh)
     uint32_t init[16]; for (int i = 0; i < 16; ++i) init[i] = i < 7 ? 0xFFFFFFFFu : 0u;
     if (!b.bbox_dev) HIPCHK(c, hipMalloc(&b.bbox_dev, 64));
-    HIPCHK(c, hipMemcpyAsync(b.bbox_dev, init, 64, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, launch_soa_repack(c->st, (const float*)b.d, n, b.soa, b.bbox_dev));
-    HIPCHK(c, hipEventRecord(c->ev_soa, c->st));
+    HIPCHK(c, hipMemcpyAsync(b.bbox_dev, init, 64, hipMemcpyHostToDevice, L.s));
+    HIPCHK(c, launch_soa_repack(L.s, (const float*)b.d, n, b.soa, b.bbox_dev));
     uint32_t got[16];
-    HIPCHK(c, hipMemcpyAsync(got, b.bbox_dev, 64, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemcpyAsync(got, b.bbox_dev, 64, hipMemcpyDeviceToHost, L.s));
+    HIPCHK(c, hipStreamSynchronize(L.s));          // the shadow is complete before any lane can be asked to read it
     auto ord2f = [](uint32_t u) { u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &u, 4); return (double)f; };
     b.bb_ok = n > 0 && got[14] == 0;
     for (int k = 0; k < 7; ++k) { b.bb_lo[k] = ord2f(got[k]); b.bb_hi[k] = ord2f(got[7 + k]); if (!(b.bb_lo[k] <= b.bb_hi[k])) b.bb_ok = false; }
@@ -157,54 +222,62 @@ int ensure_soa(gs4d_ctx* c, Buffer& b) {
     return GS4D_OK;
 }
 
-int ensure_pairs(gs4d_ctx* c, size_t cap) {
-    if (c->pair_cap >= cap) return GS4D_OK;
-    { int rc = sync_all(c); if (rc) return rc; }
-    if (c->pair_keys) (void)hipFree(c->pair_keys);
-    if (c->pair_vals) (void)hipFree(c->pair_vals);
-    c->pair_keys = c->pair_vals = nullptr; c->pair_cap = 0;
-    HIPCHK(c, hipMalloc(&c->pair_keys, cap * 4));
-    HIPCHK(c, hipMalloc(&c->pair_vals, cap * 4));
-    c->pair_cap = cap;
+// The current lane is about to use framebuffer F: order it after the lane that touched F last.
+int fb_access(gs4d_ctx* c, Framebuffer& F) {
+    if (F.last_lane >= 0 && F.last_lane != c->cur) HIPCHK(c, hipStreamWaitEvent(lane(c).s, c->lanes[F.last_lane].ev_tail, 0));
+    F.last_lane = c->cur;
     return GS4D_OK;
 }
 
-// Enqueue binning -> tile sort -> ranges -> composite on the raster stream for projected records already in c->proj.
-int enqueue_raster(gs4d_ctx* c, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, int pre_idx, uint64_t seq) {
+int materialise_fb(gs4d_ctx* c) {
+    Framebuffer& F = c->fbs[c->cur_fb];
+    if (F.is_clear) {
+        int rc = fb_access(c, F); if (rc) return rc;
+        HIPCHK(c, launch_fill(lane(c).s, F.mem, (size_t)c->W * c->H, c->clear));
+        F.is_clear = false;
+    }
+    return GS4D_OK;
+}
+
+// Enqueue binning -> tile sort -> ranges -> composite for the projected records in L.proj.
+int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
     {
-        StageTimer t(c, GS4D_T_BINNING, c->rs);
+        StageTimer t(c, GS4D_T_BINNING);
         hipError_t he = hipSuccess;
-        uint32_t* ph = sort_hist_slot(c->rs, c->pair_sort, c->pair_cap, &he);      // the emit kernel also counts the tile-id digits
+        uint32_t* ph = sort_hist_slot(L.s, L.pair_sort, L.pair_cap, &he);      // the emit kernel also counts the tile-id digits
         if (!ph) return hipfail(c, he, "sort_hist_slot");
-        HIPCHK(c, launch_binning(c->rs, c->bin, c->rects2[pre_idx], order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, c->pair_keys, c->pair_vals, c->pair_cap, c->dev_err,
-                                 ph, tile_passes, c->host_total_dev));
+        HIPCHK(c, launch_binning(L.s, L.bin, L.rects, order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, L.pair_keys, L.pair_vals, L.pair_cap, L.host_total_dev + 4,
+                                 ph, tile_passes, L.host_total_dev));
     }
-    HIPCHK(c, hipEventRecord(c->ev_emit[seq % gs4d_ctx::EMIT_RING], c->rs));     // the last binning workgroup wrote the total straight into pinned host memory
+    HIPCHK(c, hipEventRecord(L.ev_emit, L.s));     // the last binning workgroup wrote the total straight into pinned host memory
     {
-        StageTimer t(c, GS4D_T_PAIRSORT, c->rs);
-        HIPCHK(c, radix_sort_pairs(c->rs, c->pair_sort, c->pair_keys, c->pair_vals, c->pair_cap, c->bin.total, tile_bits, true));
-        HIPCHK(c, launch_tile_ranges(c->rs, c->bin, c->pair_keys, c->pair_cap, ntiles));
+        StageTimer t(c, GS4D_T_PAIRSORT);
+        HIPCHK(c, radix_sort_pairs(L.s, L.pair_sort, L.pair_keys, L.pair_vals, L.pair_cap, L.bin.total, tile_bits, true));
+        HIPCHK(c, launch_tile_ranges(L.s, L.bin, L.pair_keys, L.pair_cap, ntiles));
     }
     {
-        StageTimer t(c, GS4D_T_COMPOSITE, c->rs);
-        HIPCHK(c, launch_composite(c->rs, c->proj2[pre_idx], c->pair_vals, c->bin.ranges, c->bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, c->fb));
+        StageTimer t(c, GS4D_T_COMPOSITE);
+        HIPCHK(c, launch_composite(L.s, L.proj, L.pair_vals, L.bin.ranges, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, F.mem));
     }
-    HIPCHK(c, hipEventRecord(c->ev_raster_done[pre_idx], c->rs));
     return GS4D_OK;
 }
 
+// `preprocess` false: the re-run of a draw whose tile lists overflowed (projected records and the sort-index copy are still valid).
 int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
+    Lane& L = c->lanes[a.lane];
+    Framebuffer& F = c->fbs[a.fb];
     Buffer* data = getbuf(c, a.data);
     if (!data) return fail(c, GS4D_E_INVALID, "draw: no splat data buffer bound");
     const uint32_t* order = nullptr;
+    Buffer* ob = nullptr;
     size_t nrec = 0, npre = 0;
     int premult = 0;
     if (a.quads) { nrec = data->bytes / 288; npre = nrec < a.instances ? nrec : a.instances; premult = 1; }
     else if (a.mode == GS4D_MODE_4D_SORTED) {
-        Buffer* ob = getbuf(c, a.order);
+        ob = getbuf(c, a.order);
         if (!ob) return fail(c, GS4D_E_INVALID, "draw: GS4D_MODE_4D_SORTED needs the sort-index buffer at slot 1");
         if (ob->bytes < a.instances * 4) return fail(c, GS4D_E_INVALID, "draw: sort-index buffer smaller than the instance count");
         order = (const uint32_t*)ob->d;
@@ -215,66 +288,61 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances == 0 || nrec == 0) return GS4D_OK;
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
-    HIPCHK(c, bin_scratch_reserve(c->rs, c->bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
+    HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
     uint32_t* order_copy = nullptr;
     if (order) {
-        if (c->order_cap < a.instances) {
-            int rc = sync_all(c); if (rc) return rc;
-            if (c->order_copy) (void)hipFree(c->order_copy);
-            c->order_copy = nullptr; c->order_cap = 0;
-            HIPCHK(c, hipMalloc(&c->order_copy, a.instances * 4));
-            c->order_cap = a.instances;
+        if (L.order_cap < a.instances) {
+            HIPCHK(c, hipStreamSynchronize(L.s));
+            if (L.order_copy) (void)hipFree(L.order_copy);
+            L.order_copy = nullptr; L.order_cap = 0;
+            HIPCHK(c, hipMalloc(&L.order_copy, a.instances * 4));
+            L.order_cap = a.instances;
         }
-        if (preprocess) order_copy = c->order_copy;       // first run: the emit kernel reads the caller's buffer and keeps a copy
-        else order = c->order_copy;                        // re-run: the caller's buffer may have been overwritten since
+        if (preprocess) order_copy = L.order_copy;        // first run: the emit kernel reads the caller's buffer and keeps a copy
+        else order = L.order_copy;                         // re-run: the caller's buffer may have been overwritten since
     }
     if (preprocess) {
-        if (c->proj_cap < npre) {
-            int rc = sync_all(c); if (rc) return rc;
-            for (int i = 0; i < 2; ++i) { if (c->proj2[i]) (void)hipFree(c->proj2[i]); if (c->rects2[i]) (void)hipFree(c->rects2[i]); c->proj2[i] = nullptr; c->rects2[i] = nullptr; }
-            c->proj_cap = 0;
-            for (int i = 0; i < 2; ++i) { HIPCHK(c, hipMalloc(&c->proj2[i], npre * 64)); HIPCHK(c, hipMalloc(&c->rects2[i], npre * 8)); }
-            c->proj_cap = npre;
+        if (L.proj_cap < npre) {
+            HIPCHK(c, hipStreamSynchronize(L.s));
+            if (L.proj) (void)hipFree(L.proj);
+            if (L.rects) (void)hipFree(L.rects);
+            L.proj = nullptr; L.rects = nullptr; L.proj_cap = 0;
+            HIPCHK(c, hipMalloc(&L.proj, npre * 64)); HIPCHK(c, hipMalloc(&L.rects, npre * 8));
+            L.proj_cap = npre;
         }
         if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
-        // The projection depends on neither the sort nor the previous frame's raster stage: it has a stream of its own and two
-        // output buffers, so it runs beside the key generation / depth sort of this frame and the compositing of the last one.
-        HIPCHK(c, hipStreamWaitEvent(c->ps, c->ev_soa, 0));
-        HIPCHK(c, hipStreamWaitEvent(c->ps, c->ev_raster_done[a.pre_idx], 0));      // the draw two back, which read this buffer
+        { int rc = lane_access(c, *data, false); if (rc) return rc; data->rd_mask |= 1u << a.lane; }
+        if (ob) { int rc = lane_access(c, *ob, false); if (rc) return rc; ob->rd_mask |= 1u << a.lane; }
         {
-            StageTimer t(c, GS4D_T_PREPROCESS, c->ps);
-            const PreOut po = { c->proj2[a.pre_idx], c->rects2[a.pre_idx] };
-            if (a.quads) HIPCHK(c, launch_preprocess_3d(c->ps, (const float*)data->d, npre, a.u, c->W, c->H, po));
-            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(c->ps, (const float*)data->d, npre, a.u, c->W, c->H, po));
-            else HIPCHK(c, launch_preprocess_4d(c->ps, data->soa, npre, a.u, c->W, c->H, po));
+            StageTimer t(c, GS4D_T_PREPROCESS);
+            const PreOut po = { L.proj, L.rects };
+            if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po));
+            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po));
+            else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, npre, a.u, c->W, c->H, po));
         }
-        HIPCHK(c, hipEventRecord(c->ev_pre_done, c->ps));
-        HIPCHK(c, hipStreamWaitEvent(c->rs, c->ev_pre_done, 0));
-        c->proj_n = npre;
-        // binning reads the sort index (and any buffer the caller filled on `st` before this call)
-        HIPCHK(c, hipEventRecord(c->ev_order_ready, c->st));
-        HIPCHK(c, hipStreamWaitEvent(c->rs, c->ev_order_ready, 0));
+        L.proj_n = npre;
+        { int rc = fb_access(c, F); if (rc) return rc; }
     }
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
-    if (c->pair_cap < want) { int rc = ensure_pairs(c, want); if (rc) return rc; }
-    return enqueue_raster(c, order, order_copy, a.instances, npre, premult, a.fb_was_clear, a.pre_idx, a.seq);
+    if (L.pair_cap < want) { int rc = ensure_pairs(c, L, want); if (rc) return rc; }
+    return enqueue_raster(c, L, F, order, order_copy, a.instances, npre, premult, a.fb_was_clear);
 }
 
 // A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
-// Called by every entry point that could observe the draw's result or overwrite its inputs.  On overflow the raster stages are
-// re-run with exact capacity (the projected records are still valid; inputs are unchanged by construction).
+// Called by every entry point that could observe the draw's result.  On overflow the raster stages are re-run with exact capacity
+// (the projected records and the copy of the sort index are still valid).
 int resolve_pending(gs4d_ctx* c) {
     while (c->pending) {
-        HIPCHK(c, hipEventSynchronize(c->ev_emit[c->pending_args.seq % gs4d_ctx::EMIT_RING]));     // the entry count is final once the binning kernel has run
+        Lane& L = c->lanes[c->pending_args.lane];
+        HIPCHK(c, hipEventSynchronize(L.ev_emit));     // the entry count is final once the binning kernel has run
         c->pending = false;
-        if (c->emit_known < c->pending_args.seq) c->emit_known = c->pending_args.seq;
-        if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "radix sort: a look-back spin timed out on the device (results of this frame are invalid)");
-        const uint64_t total = (uint64_t)c->host_total[2] | ((uint64_t)c->host_total[3] << 32);
-        if (!c->host_total[1]) { c->stat_entries = total; break; }
+        if (L.host_total[4]) return fail(c, GS4D_E_DEVICE, DEVICE_CHECK_MSG);
+        const uint64_t total = (uint64_t)L.host_total[2] | ((uint64_t)L.host_total[3] << 32);
+        if (!L.host_total[1]) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)");
         c->stat_reruns++;
-        int rc = ensure_pairs(c, (size_t)(total + total / 8 + 1024));
+        int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;
         c->stat_entries = total;
         rc = run_draw(c, c->pending_args, false);
@@ -284,39 +352,24 @@ int resolve_pending(gs4d_ctx* c) {
     return GS4D_OK;
 }
 
-// Is a draw that reads buffer `B` possibly still running?  (The host may be many frames ahead of the device.)
-bool in_flight(gs4d_ctx* c, const Buffer& B) { return B.order_seq > c->done_seq || B.data_seq > c->done_seq; }
-
-// The host is about to write (or free) `B`: wait for every draw that reads it.
-int host_write_hazard(gs4d_ctx* c, const Buffer& B) {
-    if (!in_flight(c, B)) return GS4D_OK;
+int host_access(gs4d_ctx* c, Buffer& B) {
+    if (B.touch <= c->synced) return GS4D_OK;
     int rc = resolve_pending(c); if (rc) return rc;
-    return sync_all(c);
-}
-
-// The order stage is about to overwrite `b`: if the in-flight draw reads its sort index from it, wait (on the device) until the
-// binning kernel has consumed and copied it.  No host synchronisation.
-int order_write_hazard(gs4d_ctx* c, gs4d_buf b) {
-    Buffer* B = getbuf(c, b);
-    if (!B) return GS4D_OK;
-    if (B->data_seq > c->done_seq) return host_write_hazard(c, *B);          // overwriting the records of a running draw: rare, settle on the host
-    const uint64_t known = c->done_seq > c->emit_known ? c->done_seq : c->emit_known;
-    // ring slot seq % 8 holds the record of draw `seq` or of a later one: waiting for it is sufficient either way
-    if (B->order_seq > known) HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_emit[B->order_seq % gs4d_ctx::EMIT_RING], 0));
+    rc = sync_all(c); if (rc) return rc;
+    B.wr_lane = -1; B.rd_mask = 0; B.tail_mask = 0; B.ordered_mask = 0;
     return GS4D_OK;
 }
 
-int materialise_fb(gs4d_ctx* c) {
-    if (c->fb_is_clear) { HIPCHK(c, launch_fill(c->rs, c->fb, (size_t)c->W * c->H, c->clear)); c->fb_is_clear = false; }
-    return GS4D_OK;
-}
-
-int alloc_fb(gs4d_ctx* c, int w, int h) {
+int alloc_fbs(gs4d_ctx* c, int w, int h) {
     if (w <= 0 || h <= 0 || w > 65535 || h > 65535) return fail(c, GS4D_E_INVALID, "framebuffer size must be 1..65535");
-    if (c->fb) { int rc = sync_all(c); if (rc) return rc; (void)hipFree(c->fb); c->fb = nullptr; }
-    HIPCHK(c, hipMalloc(&c->fb, (size_t)w * h * 16));
+    { int rc = sync_all(c); if (rc) return rc; }
+    for (int i = 0; i < c->nlanes; ++i) {
+        if (c->fbs[i].mem) { (void)hipFree(c->fbs[i].mem); c->fbs[i].mem = nullptr; }
+        HIPCHK(c, hipMalloc(&c->fbs[i].mem, (size_t)w * h * 16));
+        c->fbs[i].is_clear = true; c->fbs[i].last_lane = -1;
+    }
     c->W = w; c->H = h; c->tiles_x = (w + TILE - 1) / TILE; c->tiles_y = (h + TILE - 1) / TILE;
-    c->fb_is_clear = true;
+    c->cur_fb = c->cur;
     return GS4D_OK;
 }
 
@@ -324,7 +377,7 @@ int alloc_fb(gs4d_ctx* c, int w, int h) {
 
 extern "C" {
 
-const char* gs4d_version(void) { return "gs4d 0.1 (gfx950)"; }
+const char* gs4d_version(void) { return "gs4d 0.2 (gfx950)"; }
 
 const char* gs4d_last_error(gs4d_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
@@ -342,26 +395,26 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     c->bufs.resize(1);
     memset(&c->u, 0, sizeof c->u);
     for (int i = 0; i < 4; ++i) c->u.view[5 * i] = c->u.proj[5 * i] = 1.0f;
+    if (const char* ev = getenv("GS4D_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) c->nlanes = v; }     // tuning knob
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
-    if ((e = hipStreamCreateWithFlags(&c->own_st, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
-    c->st = c->own_st;
-    c->single_stream = getenv("GS4D_STREAMS") && atoi(getenv("GS4D_STREAMS")) == 1;     // tuning knob (experiments only): every stage on one stream
-    if (c->single_stream) { c->rs = c->ps = c->own_st; }
-    else {
-        if ((e = hipStreamCreateWithFlags(&c->rs, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
-        if ((e = hipStreamCreateWithFlags(&c->ps, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
+    for (int i = 0; i < c->nlanes; ++i) {
+        Lane& L = c->lanes[i];
+        if ((e = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
+        for (hipEvent_t* ev : { &L.ev_emit, &L.ev_tail }) {
+            if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
+            if ((e = hipEventRecord(*ev, L.s)) != hipSuccess) return bail(hipfail(c, e, "hipEventRecord"));      // "already happened"
+        }
+        if ((e = hipHostMalloc((void**)&L.host_total, 64, hipHostMallocMapped)) != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
+        memset(L.host_total, 0, 64);
+        if ((e = hipHostGetDevicePointer((void**)&L.host_total_dev, L.host_total, 0)) != hipSuccess) return bail(hipfail(c, e, "hipHostGetDevicePointer"));
+        L.depth_sort.err = L.pair_sort.err = L.host_total_dev + 4;
     }
-    for (hipEvent_t* ev : { &c->ev_soa, &c->ev_order_ready, &c->ev_emit[0], &c->ev_emit[1], &c->ev_emit[2], &c->ev_emit[3], &c->ev_emit[4], &c->ev_emit[5], &c->ev_emit[6], &c->ev_emit[7], &c->ev_readback, &c->ev_pre_done, &c->ev_raster_done[0], &c->ev_raster_done[1] }) {
+    for (hipEvent_t* ev : { &c->ev_user, &c->ev_readback }) {
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
-        if ((e = hipEventRecord(*ev, c->st)) != hipSuccess) return bail(hipfail(c, e, "hipEventRecord"));      // "already happened"
     }
-    if ((e = hipHostMalloc((void**)&c->host_total, 64, hipHostMallocMapped)) != hipSuccess) return bail(hipfail(c, e, "hipHostMalloc"));
-    memset(c->host_total, 0, 64);
-    if ((e = hipHostGetDevicePointer((void**)&c->host_total_dev, c->host_total, 0)) != hipSuccess) return bail(hipfail(c, e, "hipHostGetDevicePointer"));
-    c->dev_err = c->host_total_dev + 4;
-    c->depth_sort.err = c->dev_err; c->pair_sort.err = c->dev_err;
-    { bool ordered = false; if ((e = lds_atomic_order_selftest(c->st, &ordered)) != hipSuccess) return bail(hipfail(c, e, "lds_atomic_order_selftest")); c->depth_sort.atomic_rank = c->pair_sort.atomic_rank = ordered; }
-    int rc = alloc_fb(c, width, height);
+    { bool ordered = false; if ((e = lds_atomic_order_selftest(c->lanes[0].s, &ordered)) != hipSuccess) return bail(hipfail(c, e, "lds_atomic_order_selftest")); c->atomic_rank = ordered; }
+    for (int i = 0; i < c->nlanes; ++i) c->lanes[i].depth_sort.atomic_rank = c->lanes[i].pair_sort.atomic_rank = c->atomic_rank;
+    int rc = alloc_fbs(c, width, height);
     if (rc) return bail(rc);
     *out = c;
     return GS4D_OK;
@@ -370,23 +423,26 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
 void gs4d_destroy(gs4d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->st) (void)hipStreamSynchronize(c->st);
-    if (c->rs) (void)hipStreamSynchronize(c->rs);
-    if (c->ps) (void)hipStreamSynchronize(c->ps);
-    if (c->order_copy) (void)hipFree(c->order_copy);
+    for (int i = 0; i < MAX_LANES; ++i) if (c->lanes[i].s) (void)hipStreamSynchronize(c->lanes[i].s);
     for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); if (b.bbox_dev) (void)hipFree(b.bbox_dev); }
-    if (c->fb) (void)hipFree(c->fb);
-    for (int i = 0; i < 2; ++i) { if (c->proj2[i]) (void)hipFree(c->proj2[i]); if (c->rects2[i]) (void)hipFree(c->rects2[i]); }
-    if (c->pair_keys) (void)hipFree(c->pair_keys);
-    if (c->pair_vals) (void)hipFree(c->pair_vals);
-    sort_scratch_free(c->depth_sort); sort_scratch_free(c->pair_sort); bin_scratch_free(c->bin);
-    if (c->host_total) (void)hipHostFree(c->host_total);
+    for (int i = 0; i < MAX_LANES; ++i) {
+        Lane& L = c->lanes[i];
+        if (c->fbs[i].mem) (void)hipFree(c->fbs[i].mem);
+        if (L.order_copy) (void)hipFree(L.order_copy);
+        if (L.proj) (void)hipFree(L.proj);
+        if (L.rects) (void)hipFree(L.rects);
+        if (L.pair_keys) (void)hipFree(L.pair_keys);
+        if (L.pair_vals) (void)hipFree(L.pair_vals);
+        sort_scratch_free(L.depth_sort); sort_scratch_free(L.pair_sort); bin_scratch_free(L.bin);
+        if (L.host_total) (void)hipHostFree(L.host_total);
+        if (L.ev_emit) (void)hipEventDestroy(L.ev_emit);
+        if (L.ev_tail) (void)hipEventDestroy(L.ev_tail);
+        if (L.s) (void)hipStreamDestroy(L.s);
+    }
     for (auto e : c->ev0) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev1) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t ev : { c->ev_soa, c->ev_order_ready, c->ev_emit[0], c->ev_emit[1], c->ev_emit[2], c->ev_emit[3], c->ev_emit[4], c->ev_emit[5], c->ev_emit[6], c->ev_emit[7], c->ev_readback, c->ev_pre_done, c->ev_raster_done[0], c->ev_raster_done[1] }) if (ev) (void)hipEventDestroy(ev);
-    if (c->rs && !c->single_stream) (void)hipStreamDestroy(c->rs);
-    if (c->ps && !c->single_stream) (void)hipStreamDestroy(c->ps);
-    if (c->own_st) (void)hipStreamDestroy(c->own_st);
+    if (c->ev_user) (void)hipEventDestroy(c->ev_user);
+    if (c->ev_readback) (void)hipEventDestroy(c->ev_readback);
     delete c;
 }
 
@@ -395,7 +451,7 @@ int gs4d_resize(gs4d_ctx* c, int width, int height) {
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
     if (width == c->W && height == c->H) return GS4D_OK;
-    return alloc_fb(c, width, height);
+    return alloc_fbs(c, width, height);
 }
 
 // ---- buffers ----
@@ -408,7 +464,7 @@ int gs4d_buffer_create(gs4d_ctx* c, const void* data, size_t bytes, gs4d_buf* ou
     Buffer nb;
     if (bytes) {
         HIPCHK(c, hipMalloc(&nb.d, bytes));
-        if (data) { hipError_t e = hipMemcpyAsync(nb.d, data, bytes, hipMemcpyHostToDevice, c->st); if (e == hipSuccess) e = hipStreamSynchronize(c->st); if (e != hipSuccess) { (void)hipFree(nb.d); return hipfail(c, e, "buffer upload"); } }
+        if (data) { hipError_t e = hipMemcpy(nb.d, data, bytes, hipMemcpyHostToDevice); if (e != hipSuccess) { (void)hipFree(nb.d); return hipfail(c, e, "buffer upload"); } }
     }
     nb.bytes = bytes; nb.alive = true; nb.version = 1;
     c->bufs[name] = nb;
@@ -424,10 +480,9 @@ int gs4d_buffer_subdata(gs4d_ctx* c, gs4d_buf b, size_t offset, const void* data
     if (offset > B->bytes || bytes > B->bytes - offset) return fail(c, GS4D_E_INVALID, "buffer_subdata: range outside the buffer");   // GL_INVALID_VALUE
     if (!bytes) return GS4D_OK;
     if (!data) return fail(c, GS4D_E_INVALID, "buffer_subdata: data == NULL");
-    { int rc = host_write_hazard(c, *B); if (rc) return rc; }
+    { int rc = host_access(c, *B); if (rc) return rc; }
     // the caller keeps ownership of `data` and may reuse it on return (glBufferSubData semantics): copy synchronously
-    HIPCHK(c, hipMemcpyAsync((char*)B->d + offset, data, bytes, hipMemcpyHostToDevice, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    HIPCHK(c, hipMemcpy((char*)B->d + offset, data, bytes, hipMemcpyHostToDevice));
     B->version++;
     return GS4D_OK;
 }
@@ -439,8 +494,11 @@ int gs4d_buffer_read(gs4d_ctx* c, gs4d_buf b, size_t offset, void* out, size_t b
     if (!B) return fail(c, GS4D_E_INVALID, "buffer_read: bad buffer name");
     if (offset > B->bytes || bytes > B->bytes - offset || (!out && bytes)) return fail(c, GS4D_E_INVALID, "buffer_read: range outside the buffer");
     if (!bytes) return GS4D_OK;
-    HIPCHK(c, hipMemcpyAsync(out, (const char*)B->d + offset, bytes, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(c, hipStreamSynchronize(c->st));
+    // after the kernels that wrote it: they sit on the current lane, or on the lane recorded in the buffer
+    HIPCHK(c, hipStreamSynchronize(lane(c).s));
+    if (B->wr_lane >= 0 && B->wr_lane != c->cur) HIPCHK(c, hipStreamSynchronize(c->lanes[B->wr_lane].s));
+    HIPCHK(c, hipMemcpy(out, (const char*)B->d + offset, bytes, hipMemcpyDeviceToHost));
+    if (device_error(c)) return fail(c, GS4D_E_DEVICE, DEVICE_CHECK_MSG);
     return GS4D_OK;
 }
 
@@ -455,7 +513,7 @@ int gs4d_buffer_destroy(gs4d_ctx* c, gs4d_buf b) {
     if (B->bbox_dev) (void)hipFree(B->bbox_dev);
     *B = Buffer();
     for (auto& s : c->slots) if (s == b) s = 0;     // a deleted buffer is unbound
-    if (c->kg_buf == b) c->kg_buf = 0;
+    for (int i = 0; i < c->nlanes; ++i) if (c->lanes[i].kg_buf == b) c->lanes[i].kg_buf = 0;
     return GS4D_OK;
 }
 
@@ -496,7 +554,7 @@ int gs4d_set_uniform_mat4(gs4d_ctx* c, int id, const float m[16]) {
 int gs4d_set_clear_color(gs4d_ctx* c, const float rgba[4]) {
     if (!c || !rgba) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
-    if (c->fb_is_clear && memcmp(c->clear, rgba, 16) != 0) { int rc = materialise_fb(c); if (rc) return rc; }  // glClearColor does not touch pixels
+    if (c->fbs[c->cur_fb].is_clear && memcmp(c->clear, rgba, 16) != 0) { int rc = materialise_fb(c); if (rc) return rc; }  // glClearColor does not touch pixels
     memcpy(c->clear, rgba, 16); return GS4D_OK;
 }
 int gs4d_set_blend(gs4d_ctx* c, int src, int dst) {
@@ -506,9 +564,14 @@ int gs4d_set_blend(gs4d_ctx* c, int src, int dst) {
 }
 int gs4d_clear(gs4d_ctx* c) {
     if (!c) return GS4D_E_INVALID;
-    // Whatever a still-unvalidated draw left in the framebuffer is discarded by the clear; its inputs are no longer needed.
+    (void)hipSetDevice(c->device);
+    // Whatever a still-unvalidated draw left in the framebuffer is discarded by the clear.
     c->pending = false;
-    c->fb_is_clear = true;
+    int rc = next_frame_if_drawn(c); if (rc) return rc;
+    // the new frame renders into the current lane's own framebuffer (a swap chain with one image per lane); the clear itself is
+    // lazy: the compositing kernel starts from the clear colour instead of reading the pixels
+    c->cur_fb = c->cur;
+    c->fbs[c->cur_fb].is_clear = true;
     return GS4D_OK;
 }
 
@@ -521,11 +584,13 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     if (!K || !V) return fail(c, GS4D_E_INVALID, "sort_pairs: bad buffer name");
     if (K == V) return fail(c, GS4D_E_INVALID, "sort_pairs: keys and values must be different buffers");
     if (n >= 0xFFFFFFFFull || K->bytes < n * 4 || V->bytes < n * 4) return fail(c, GS4D_E_INVALID, "sort_pairs: buffers smaller than n elements");
-    { int rc = order_write_hazard(c, keys); if (rc) return rc; rc = order_write_hazard(c, vals); if (rc) return rc; }
+    { int rc = next_frame_if_drawn(c); if (rc) return rc; rc = after_user_stream(c); if (rc) return rc; }
+    { int rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *V, true); if (rc) return rc; }
+    Lane& L = lane(c);
     // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
-    const bool have_hist = c->depth_sort.hist_pending && keys == c->kg_buf && K->version == c->kg_ver && n == c->kg_n;
+    const bool have_hist = L.depth_sort.hist_pending && keys == L.kg_buf && K->version == L.kg_ver && n == L.kg_n;
     StageTimer t(c, GS4D_T_SORT);
-    HIPCHK(c, radix_sort_pairs(c->st, c->depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, have_hist ? c->depth_sort.hist_bits : 32, have_hist));
+    HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, have_hist ? L.depth_sort.hist_bits : 32, have_hist));
     K->version++; V->version++;
     return GS4D_OK;
 }
@@ -538,16 +603,18 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     if (key_mode != GS4D_KEY_REF_INV_EUCLID && key_mode != GS4D_KEY_VIEW_Z) return fail(c, GS4D_E_INVALID, "keygen: unknown key mode");
     if (n >= 0xFFFFFFFFull || D->bytes < n * 96 || K->bytes < n * 4 || I->bytes < n * 4) return fail(c, GS4D_E_INVALID, "keygen: buffers smaller than n elements");
     if (n == 0) return GS4D_OK;
-    { int rc = order_write_hazard(c, keys); if (rc) return rc; rc = order_write_hazard(c, idx); if (rc) return rc; }
+    { int rc = next_frame_if_drawn(c); if (rc) return rc; rc = after_user_stream(c); if (rc) return rc; }
     int rc = ensure_soa(c, *D); if (rc) return rc;
+    { rc = lane_access(c, *D, false); if (rc) return rc; D->tail_mask |= 1u << c->cur; rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *I, true); if (rc) return rc; }
+    Lane& L = lane(c);
     hipError_t he = hipSuccess;
-    uint32_t* kh = sort_hist_slot(c->st, c->depth_sort, n, &he);
+    uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, n, &he);
     if (!kh) return hipfail(c, he, "sort_hist_slot");
     // A proven lower bound of every key (1 / farthest possible distance, from the bounding box of the records) is subtracted inside
     // the sort's digit extraction: when the keys span less than 2^24 bit patterns above it (camera outside the cloud, far/near < 4)
-    // the top digit becomes constant and its pass is skipped on the device.  k_keygen re-checks the bound for every key.
-    // When the camera is provably outside the box the same reasoning gives an upper bound, hence the number of key bits above the
-    // bias: with <= 24 the sort is launched with three passes instead of four (no launch for the constant digit at all).
+    // the top digit becomes constant.  When the camera is provably outside the box the same reasoning gives an upper bound, hence
+    // the number of key bits above the bias: with <= 24 the sort is launched with three passes instead of four.  k_keygen re-checks
+    // both bounds for every key and raises the error word if one does not hold.
     uint32_t bias = 0, span = 0xFFFFFFFFu;
     if (key_mode == GS4D_KEY_REF_INV_EUCLID && D->bb_ok) {          // the box covers all records of the buffer, a superset of the n keyed
         const double c_lo = (double)t - D->bb_hi[3], c_hi = (double)t - D->bb_lo[3];
@@ -575,11 +642,11 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
         }
     }
     StageTimer tm(c, GS4D_T_KEYGEN);
-    HIPCHK(c, launch_keygen(c->st, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d, kh, bias, span, c->dev_err));
-    c->depth_sort.hist_bias = bias;
-    c->depth_sort.hist_bits = span < (1u << 8) ? 8 : span < (1u << 16) ? 16 : span < (1u << 24) ? 24 : 32;
+    HIPCHK(c, launch_keygen(L.s, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d, kh, bias, span, L.host_total_dev + 4));
+    L.depth_sort.hist_bias = bias;
+    L.depth_sort.hist_bits = span < (1u << 8) ? 8 : span < (1u << 16) ? 16 : span < (1u << 24) ? 24 : 32;
     K->version++; I->version++;
-    c->kg_buf = keys; c->kg_ver = K->version; c->kg_n = n;
+    L.kg_buf = keys; L.kg_ver = K->version; L.kg_n = n;
     return GS4D_OK;
 }
 
@@ -587,16 +654,16 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
 static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    Buffer* d = getbuf(c, a.data); Buffer* o = getbuf(c, a.order);
-    a.data_version = d ? d->version : 0; a.order_version = o ? o->version : 0;
-    a.fb_was_clear = c->fb_is_clear;
-    a.pre_idx = c->pre_idx ^ 1;
-    a.seq = c->draw_seq + 1;
-    const size_t before = c->proj_n;
-    c->proj_n = 0;
+    rc = after_user_stream(c); if (rc) return rc;
+    Lane& L = lane(c);
+    a.lane = c->cur; a.fb = c->cur_fb;
+    a.fb_was_clear = c->fbs[c->cur_fb].is_clear;
+    const size_t before = L.proj_n;
+    L.proj_n = 0;
     rc = run_draw(c, a, true);
-    if (rc) { c->proj_n = before; return rc; }
-    if (c->proj_n) { c->pending = true; c->pending_args = a; c->fb_is_clear = false; c->pre_idx = a.pre_idx; c->draw_seq = a.seq; if (d) d->data_seq = a.seq; if (o && a.mode == GS4D_MODE_4D_SORTED && !a.quads) o->order_seq = a.seq; }   // proj_n != 0 <=> raster work was enqueued
+    if (rc) { L.proj_n = before; return rc; }
+    if (L.proj_n) { c->pending = true; c->pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; }   // proj_n != 0 <=> raster work was enqueued
+    else L.proj_n = before;
     if (c->profiling && c->prof_frame < gs4d_ctx::PROF_FRAMES) c->prof_frame++;
     return GS4D_OK;
 }
@@ -623,7 +690,7 @@ int gs4d_finish(gs4d_ctx* c) {
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
     rc = sync_all(c); if (rc) return rc;
-    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "device-side check failed (a bounded look-back wait timed out, or a sort key fell below its proven bound): results are invalid");
+    if (device_error(c)) return fail(c, GS4D_E_DEVICE, DEVICE_CHECK_MSG);
     return GS4D_OK;
 }
 
@@ -633,9 +700,27 @@ int gs4d_read_pixels(gs4d_ctx* c, float* rgba, size_t bytes) {
     if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels: bytes != width*height*16");
     int rc = resolve_pending(c); if (rc) return rc;
     rc = materialise_fb(c); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(rgba, c->fb, bytes, hipMemcpyDeviceToHost, c->rs));
-    HIPCHK(c, hipStreamSynchronize(c->rs));
-    if (c->host_total[4]) return fail(c, GS4D_E_DEVICE, "device-side check failed (a bounded look-back wait timed out, or a sort key fell below its proven bound): results are invalid");
+    Framebuffer& F = c->fbs[c->cur_fb];
+    rc = fb_access(c, F); if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(rgba, F.mem, bytes, hipMemcpyDeviceToHost, lane(c).s));
+    HIPCHK(c, hipStreamSynchronize(lane(c).s));
+    if (device_error(c)) return fail(c, GS4D_E_DEVICE, DEVICE_CHECK_MSG);
+    return GS4D_OK;
+}
+
+static int read_device_common(gs4d_ctx* c, void* dptr, bool rgba8) {
+    int rc = resolve_pending(c); if (rc) return rc;
+    rc = after_user_stream(c); if (rc) return rc;          // the destination may still be in use by the caller's earlier work
+    rc = materialise_fb(c); if (rc) return rc;
+    Framebuffer& F = c->fbs[c->cur_fb];
+    rc = fb_access(c, F); if (rc) return rc;
+    Lane& L = lane(c);
+    if (rgba8) HIPCHK(c, launch_pack_rgba8(L.s, F.mem, (size_t)c->W * c->H, (uint32_t*)dptr));
+    else HIPCHK(c, hipMemcpyAsync(dptr, F.mem, (size_t)c->W * c->H * 16, hipMemcpyDeviceToDevice, L.s));
+    if (c->user) {                                          // work the caller queues on its stream after this call sees the pixels
+        HIPCHK(c, hipEventRecord(c->ev_readback, L.s));
+        HIPCHK(c, hipStreamWaitEvent(c->user, c->ev_readback, 0));
+    }
     return GS4D_OK;
 }
 
@@ -643,33 +728,22 @@ int gs4d_read_pixels_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (!c || !dptr) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels_device: bytes != width*height*16");
-    int rc = resolve_pending(c); if (rc) return rc;
-    rc = materialise_fb(c); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(dptr, c->fb, bytes, hipMemcpyDeviceToDevice, c->rs));
-    HIPCHK(c, hipEventRecord(c->ev_readback, c->rs));
-    HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_readback, 0));      // work the caller queues on `st` after this call sees the pixels
-    return GS4D_OK;
+    return read_device_common(c, dptr, false);
 }
 
 int gs4d_read_pixels_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (!c || !dptr) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_pixels_rgba8_device: bytes != width*height*4");
-    int rc = resolve_pending(c); if (rc) return rc;
-    rc = materialise_fb(c); if (rc) return rc;
-    HIPCHK(c, launch_pack_rgba8(c->rs, c->fb, (size_t)c->W * c->H, (uint32_t*)dptr));
-    HIPCHK(c, hipEventRecord(c->ev_readback, c->rs));
-    HIPCHK(c, hipStreamWaitEvent(c->st, c->ev_readback, 0));      // work the caller queues on `st` after this call sees the pixels
-    return GS4D_OK;
+    return read_device_common(c, dptr, true);
 }
 
 int gs4d_set_stream(gs4d_ctx* c, void* hip_stream) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    rc = sync_all(c); if (rc) return rc;             // everything queued so far completes before work moves to the other stream
-    c->st = hip_stream ? (hipStream_t)hip_stream : c->own_st;
-    if (c->single_stream) c->rs = c->ps = c->st;
+    rc = sync_all(c); if (rc) return rc;             // everything queued so far completes before the ordering contract changes
+    c->user = (hipStream_t)hip_stream;
     return GS4D_OK;
 }
 
@@ -737,17 +811,18 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[4]) {
     if (!c || !stats) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    stats[0] = c->stat_entries; stats[1] = c->pair_cap; stats[2] = c->stat_reruns; stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
+    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = c->stat_reruns; stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
     return GS4D_OK;
 }
 
 int gs4d_debug_read_projected(gs4d_ctx* c, float* out16, size_t nrecords) {
     if (!c || !out16) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
-    if (nrecords > c->proj_n) return fail(c, GS4D_E_INVALID, "debug_read_projected: more records than the last draw projected");
+    Lane& L = lane(c);
+    if (nrecords > L.proj_n) return fail(c, GS4D_E_INVALID, "debug_read_projected: more records than the last draw projected");
     int rc = resolve_pending(c); if (rc) return rc;
-    HIPCHK(c, hipMemcpyAsync(out16, c->proj2[c->pre_idx], nrecords * 64, hipMemcpyDeviceToHost, c->rs));
-    HIPCHK(c, hipStreamSynchronize(c->rs));
+    HIPCHK(c, hipMemcpyAsync(out16, L.proj, nrecords * 64, hipMemcpyDeviceToHost, L.s));
+    HIPCHK(c, hipStreamSynchronize(L.s));
     // expose the layout documented in gs4d.h: cx,cy,a0x,a0y,a1x,a1y,alpha,r,g,b,rect0,rect1,hx,hy,valid,0  (already the storage order)
     return GS4D_OK;
 }

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--splats", type=int, default=1_000_000)
+    ap.add_argument("--keybufs", type=int, default=2, help="per-frame key / sort-index buffer pairs the application cycles through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
     args = ap.parse_args()
@@ -84,12 +85,14 @@ def main():
         rec = gs4d.build_records_3d(pos, q, scale, rgba)
 
     ctx = gs4d.Context(W, H, device=local_rank)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)          # HIP stream shared with torch so that the gather orders after the draw
+    if multi:
+        # torch's stream becomes the caller's stream: the packed frame is ordered before the gather that sends it, and the next
+        # frame's pack after the gather that still reads the buffer
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     data = ctx.buffer(rec)
     # per-frame key / sort-index buffers are double-buffered by the application (as any renderer does with per-frame resources):
     # frame f+1 can generate and sort its keys while frame f's binning still reads frame f's sort index
-    keybufs = [(ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)) for _ in range(2)]
+    keybufs = [(ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)) for _ in range(args.keybufs)]
     ctx.set_clear_color(gs4d.CLEAR_COLOR)
     ctx.set_mode(gs4d.MODE_4D_SORTED)
     ctx.bind(2, data)
@@ -107,7 +110,7 @@ def main():
     def step(k):
         # frame of this rank in the time sweep (frame f -> rank f mod world); static 3D records ignore t
         t = sharding.sweep_time(sharding.frame_of(k, rank, world), total_frames) if multi else 0.0
-        keys, idx = keybufs[k & 1]
+        keys, idx = keybufs[k % args.keybufs]
         ctx.clear()
         ctx.set_uniforms(time=t)
         ctx.keygen(data, t, cam[0], keys, idx, n)
