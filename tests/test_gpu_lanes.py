@@ -1,0 +1,151 @@
+"""GPU: frames queued back to back without host synchronisation land on different frame lanes (streams).  Whatever the call order
+and however the application recycles its buffers, every frame that is read back must equal the CPU checker's.
+
+Reference loop being replayed: Scene::Update (key loop + sort, Scenes.h:312-327) then Renderer::Clear / Draw (Renderer.cpp:20-39) —
+i.e. the sort is issued BEFORE the clear; the other tests issue clear first.  Bar: image L-inf <= 1e-4 (float), as in test_gpu_render.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+W, H = 640, 360
+CAM = scenes.CAM_CUBE
+
+
+def _mats(gs4d):
+    return gs4d.look_at(CAM[0], CAM[1]), gs4d.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
+
+
+def _records(gs4d, n=30000):
+    pos4, q, scale, life, fade, vel, rgba = scenes.cube_params_4d(n)
+    return gs4d.build_records_4d(pos4, q, scale * 4.0, life, fade, vel, rgba)
+
+
+def _expected(oracle, rec, t, view, proj):
+    return oracle.render_4d(rec, True, t, 0.0, CAM[0], view, proj, W, H)[0]
+
+
+@pytest.fixture(params=[1, 2, 3, 4])
+def lanes_ctx(request, gs4d):
+    old = os.environ.get("GS4D_LANES")
+    os.environ["GS4D_LANES"] = str(request.param)          # read by gs4d_create
+    ctx = gs4d.Context(W, H)
+    if old is None:
+        del os.environ["GS4D_LANES"]
+    else:
+        os.environ["GS4D_LANES"] = old
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("keybufs", [1, 2, 3])
+@pytest.mark.parametrize("sort_first", [False, True])
+def test_frames_in_flight_recycled_buffers(lanes_ctx, gs4d, oracle, keybufs, sort_first):
+    """Many frames in flight, each at another time; the application cycles through 1, 2 or 3 key/index buffer pairs, so a later
+    frame's key generation overwrites what an earlier frame's binning still has to read (on another lane)."""
+    ctx = lanes_ctx
+    rec = _records(gs4d)
+    n = rec.shape[0]
+    view, proj = _mats(gs4d)
+    data = ctx.buffer(rec)
+    kb = [(ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)) for _ in range(keybufs)]
+    ctx.bind(2, data)
+    times = [0.0, 7.0, 14.0, 21.0, 28.0, 35.0, 42.0]
+    check = {2, 5, 6}                                       # frames read back (the others stay unobserved and in flight)
+    for f, t in enumerate(times):
+        keys, idx = kb[f % keybufs]
+        if not sort_first:
+            ctx.clear()
+        ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+        ctx.keygen(data, t, CAM[0], keys, idx, n)
+        ctx.sort_pairs(keys, idx, n)
+        if sort_first:
+            ctx.clear()                                     # Scene::Update before Renderer::Clear
+        ctx.bind(1, idx)
+        ctx.draw_instanced(n)
+        if f in check:
+            img = ctx.read_pixels()
+            assert np.max(np.abs(img - _expected(oracle, rec, t, view, proj))) <= TOL, f"frame {f}"
+    ctx.finish()
+
+
+def test_draws_accumulate_across_lanes(lanes_ctx, gs4d, oracle):
+    """No Clear between two sorted draws: the second frame's order stage starts a new lane, its composite must still blend onto the
+    first draw's pixels (same framebuffer, other stream)."""
+    ctx = lanes_ctx
+    view, proj = _mats(gs4d)
+    recs, eimg = [], oracle.clear_image(W, H)
+    ctx.clear()
+    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+    for seed in (5, 6, 7):
+        pos, q, scale, rgba = scenes.cube_params(8000, seed=seed)
+        rec = gs4d.build_records_3d(pos, q, scale * 6.0, rgba)
+        n = rec.shape[0]
+        data, keys, idx = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+        ctx.keygen(data, 0.0, CAM[0], keys, idx, n)
+        ctx.sort_pairs(keys, idx, n)
+        ctx.bind(2, data)
+        ctx.bind(1, idx)
+        ctx.draw_instanced(n)
+        _, ekeys = oracle.keygen(rec, 0.0, CAM[0])
+        _, eperm = oracle.sort_pairs(ekeys.view(np.uint32), np.arange(n, dtype=np.uint32), "lsd")
+        oracle.composite(oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H), eperm, oracle.MODE_4D, W, H, eimg)
+    assert np.max(np.abs(ctx.read_pixels() - eimg)) <= TOL
+    # the next cleared frame does not see any of it
+    ctx.clear()
+    assert np.array_equal(ctx.read_pixels(), oracle.clear_image(W, H))
+
+
+def test_sort_output_consumed_on_another_lane(lanes_ctx, gs4d, oracle):
+    """A sort index produced during one frame (after its draw) and drawn in the next: written on one lane, read on the next."""
+    ctx = lanes_ctx
+    rec = _records(gs4d, 12000)
+    n = rec.shape[0]
+    view, proj = _mats(gs4d)
+    data = ctx.buffer(rec)
+    a = (ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n))
+    b = (ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n))
+    ctx.bind(2, data)
+    ctx.keygen(data, 3.0, CAM[0], *a, n)
+    ctx.sort_pairs(*a, n)
+    for f, t in enumerate((3.0, 9.0, 15.0, 21.0)):
+        cur, nxt = (a, b) if f % 2 == 0 else (b, a)
+        ctx.clear()
+        ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+        ctx.bind(1, cur[1])
+        ctx.draw_instanced(n)
+        ctx.keygen(data, t + 6.0, CAM[0], *nxt, n)          # next frame's order, queued behind this frame's draw
+        ctx.sort_pairs(*nxt, n)
+        if f >= 2:
+            assert np.max(np.abs(ctx.read_pixels() - _expected(oracle, rec, t, view, proj))) <= TOL, f"frame {f}"
+    ctx.finish()
+
+
+def test_subdata_while_frames_in_flight(lanes_ctx, gs4d, oracle):
+    """glBufferSubData on the splat records while earlier frames are still queued: they must finish with the old data first."""
+    ctx = lanes_ctx
+    rec = _records(gs4d, 15000)
+    n = rec.shape[0]
+    view, proj = _mats(gs4d)
+    data, keys, idx = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.bind(2, data)
+    ctx.set_uniforms(time=5.0, min_opacity=0.0, view=view, proj=proj)
+    rec2 = rec.copy()
+    rec2[: n // 2, 0:3] *= 0.5
+    for r in (rec, rec2, rec):
+        ctx.subdata(data, r)
+        for _ in range(3):
+            ctx.clear()
+            ctx.keygen(data, 5.0, CAM[0], keys, idx, n)
+            ctx.sort_pairs(keys, idx, n)
+            ctx.bind(1, idx)
+            ctx.draw_instanced(n)
+        assert np.max(np.abs(ctx.read_pixels() - _expected(oracle, r, 5.0, view, proj))) <= TOL
+    ctx.finish()
