@@ -311,9 +311,10 @@ class Context:
         return ms[:n.value]
 
     def stats(self):
-        st = np.zeros(4, np.uint64)
+        st = np.zeros(8, np.uint64)
         self._chk(_lib.gs4d_get_stats(self._h, _ptr(st)))
-        return {"entries": int(st[0]), "capacity": int(st[1]), "reruns": int(st[2]), "tiles": int(st[3])}
+        return {"entries": int(st[0]), "capacity": int(st[1]), "reruns": int(st[2]), "tiles": int(st[3]),
+                "depth_sort_passes": int(st[4]), "tile_sort_passes": int(st[5]), "lanes": int(st[6])}
 
     def debug_projected(self, n):
         out = np.empty((n, 16), np.float32)

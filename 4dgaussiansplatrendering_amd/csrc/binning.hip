@@ -181,19 +181,26 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
     if (tid < 256u) os_hist_flush(h, ghist, passes, tid);
 }
 
+// ranges[2t], ranges[2t+1] = first and one-past-last entry of tile t in the sorted tile lists.  Four entries per thread.
 __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict__ pk, const uint32_t* __restrict__ total, uint32_t ntiles, uint32_t* __restrict__ ranges) {
     if (total[1]) return;
     const uint32_t m = total[0];
-    uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= m) return;
-    uint32_t cur = pk[j];
-    if (cur >= ntiles) return;
-    if (j == 0) ranges[2 * cur] = 0;
-    else {
-        uint32_t prev = pk[j - 1];
-        if (prev != cur) { ranges[2 * cur] = j; if (prev < ntiles) ranges[2 * prev + 1] = j; }
+    const uint32_t j0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (j0 >= m) return;
+    uint32_t k[4];
+    if (j0 + 4u <= m) { const uint4 v = *reinterpret_cast<const uint4*>(pk + j0); k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w; }
+    else { for (int q = 0; q < 4; ++q) k[q] = j0 + q < m ? pk[j0 + q] : 0xFFFFFFFFu; }
+    uint32_t prev = j0 ? pk[j0 - 1u] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t j = j0 + q, cur = k[q];
+        if (j < m && cur < ntiles) {
+            if (j == 0) ranges[2 * cur] = 0;
+            else if (prev != cur) { ranges[2 * cur] = j; if (prev < ntiles) ranges[2 * prev + 1] = j; }
+            if (j == m - 1) ranges[2 * cur + 1] = m;
+        }
+        prev = cur;
     }
-    if (j == m - 1) ranges[2 * cur + 1] = m;
 }
 
 hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size_t ntiles) {
@@ -241,7 +248,7 @@ hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, con
 }
 
 hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pair_keys, size_t pair_cap, size_t ntiles) {
-    k_tile_ranges<<<dim3((unsigned)((pair_cap + 255) / 256)), dim3(256), 0, st>>>(pair_keys, b.total, (uint32_t)ntiles, b.ranges);
+    k_tile_ranges<<<dim3((unsigned)((pair_cap + 1023) / 1024)), dim3(256), 0, st>>>(pair_keys, b.total, (uint32_t)ntiles, b.ranges);
     return hipGetLastError();
 }
 

@@ -101,7 +101,7 @@ struct gs4d_ctx {
     uint64_t ops = 0, synced = 0;      // device-side uses so far / at the last sync of every lane
     bool pending = false;              // the last draw's tile-list capacity has not been validated yet
     DrawArgs pending_args;
-    uint64_t stat_entries = 0, stat_reruns = 0;
+    uint64_t stat_entries = 0, stat_reruns = 0, stat_depth_passes = 0, stat_tile_passes = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
     static constexpr int PROF_FRAMES = 128;
     unsigned profiling = 0;                    // bit s set: stage s is timed
@@ -256,10 +256,11 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, 
     {
         StageTimer t(c, GS4D_T_PAIRSORT);
         HIPCHK(c, radix_sort_pairs(L.s, L.pair_sort, L.pair_keys, L.pair_vals, L.pair_cap, L.bin.total, tile_bits, true));
-        HIPCHK(c, launch_tile_ranges(L.s, L.bin, L.pair_keys, L.pair_cap, ntiles));
     }
+    c->stat_tile_passes = (uint64_t)tile_passes;
     {
-        StageTimer t(c, GS4D_T_COMPOSITE);
+        StageTimer t(c, GS4D_T_COMPOSITE);      // the per-tile ranges and the compositing kernel
+        HIPCHK(c, launch_tile_ranges(L.s, L.bin, L.pair_keys, L.pair_cap, ntiles));
         HIPCHK(c, launch_composite(L.s, L.proj, L.pair_vals, L.bin.ranges, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, F.mem));
     }
     return GS4D_OK;
@@ -589,8 +590,10 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     Lane& L = lane(c);
     // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
     const bool have_hist = L.depth_sort.hist_pending && keys == L.kg_buf && K->version == L.kg_ver && n == L.kg_n;
+    const int key_bits = have_hist ? L.depth_sort.hist_bits : 32;
+    c->stat_depth_passes = (uint64_t)std::max(2, (key_bits + 7) / 8);
     StageTimer t(c, GS4D_T_SORT);
-    HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, have_hist ? L.depth_sort.hist_bits : 32, have_hist));
+    HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, key_bits, have_hist));
     K->version++; V->version++;
     return GS4D_OK;
 }
@@ -807,11 +810,12 @@ int gs4d_get_timeline(gs4d_ctx* c, float* ms, int max_frames, int* frames_out) {
     return GS4D_OK;
 }
 
-int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[4]) {
+int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     if (!c || !stats) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
     stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = c->stat_reruns; stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
+    stats[4] = c->stat_depth_passes; stats[5] = c->stat_tile_passes; stats[6] = (uint64_t)c->nlanes; stats[7] = 0;
     return GS4D_OK;
 }
 

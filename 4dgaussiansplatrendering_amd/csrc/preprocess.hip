@@ -8,6 +8,7 @@
 // Compiled with -ffp-contract=off and hipcc's default IEEE divide/sqrt: everything that decides pixel coverage
 // (cx, cy, a0, a1) is bit-identical to the CPU checker, which evaluates the same expressions in the same order.
 #include "gs4d_internal.h"
+#include <algorithm>
 
 namespace gs4d {
 
@@ -20,45 +21,60 @@ __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_
 __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ soa, uint32_t* __restrict__ bbox) {
     // one wave moves 64 records = 384 float4, read fully coalesced, written as 6 x 64 contiguous float4
     __shared__ float4 stage[4][384];
+    __shared__ uint32_t red[4][16];
     const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-    const uint32_t rec0 = (blockIdx.x * 4u + w) * 64u;
-    const uint32_t nrec = rec0 < n ? min(64u, n - rec0) : 0u;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        uint32_t f = j * 64u + lane;
-        if (f < nrec * 6u) stage[w][f] = aos[(size_t)rec0 * 6u + f];
-    }
-    __syncthreads();
-    float q[7];
-    bool have = lane < nrec;
-    if (have) {
-#pragma unroll
-        for (int p = 0; p < 6; ++p) soa[(size_t)p * n + rec0 + lane] = stage[w][lane * 6u + p];
-        const float4 ps = stage[w][lane * 6u + 0], s3 = stage[w][lane * 6u + 5];
-        q[0] = ps.x; q[1] = ps.y; q[2] = ps.z; q[3] = ps.w; q[4] = s3.x; q[5] = s3.y; q[6] = s3.z;
-    }
-    bool bad = false;
+    // bounding box: accumulated in registers over the workgroup's whole share of the records, reduced once per workgroup, and only
+    // then merged into the 15 global words (they share a cache line: one atomic per wave and chunk made the kernel 30x slower)
     uint32_t lo[7], hi[7];
 #pragma unroll
+    for (int k = 0; k < 7; ++k) { lo[k] = 0xFFFFFFFFu; hi[k] = 0u; }
+    bool bad = false;
+    for (uint32_t chunk = blockIdx.x; chunk * 256u < n; chunk += gridDim.x) {           // uniform trip count per workgroup
+        const uint32_t rec0 = (chunk * 4u + w) * 64u;
+        const uint32_t nrec = rec0 < n ? min(64u, n - rec0) : 0u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            uint32_t f = j * 64u + lane;
+            if (f < nrec * 6u) stage[w][f] = aos[(size_t)rec0 * 6u + f];
+        }
+        __builtin_amdgcn_wave_barrier();               // stage[w] is private to the wave
+        if (lane < nrec) {
+#pragma unroll
+            for (int p = 0; p < 6; ++p) soa[(size_t)p * n + rec0 + lane] = stage[w][lane * 6u + p];
+            const float4 ps = stage[w][lane * 6u + 0], s3 = stage[w][lane * 6u + 5];
+            const float q[7] = { ps.x, ps.y, ps.z, ps.w, s3.x, s3.y, s3.z };
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                if (isfinite(q[k])) { const uint32_t o = f2ord(q[k]); lo[k] = min(lo[k], o); hi[k] = max(hi[k], o); }
+                else bad = true;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
     for (int k = 0; k < 7; ++k) {
-        const bool fin = have && isfinite(q[k]);
-        bad = bad || (have && !fin);
-        lo[k] = fin ? f2ord(q[k]) : 0xFFFFFFFFu;
-        hi[k] = fin ? f2ord(q[k]) : 0u;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { lo[k] = min(lo[k], (uint32_t)__shfl_xor(lo[k], off, 64)); hi[k] = max(hi[k], (uint32_t)__shfl_xor(hi[k], off, 64)); }
     }
     const bool anybad = __ballot(bad) != 0ull;
-    if (lane == 0 && nrec) {
+    if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) { atomicMin(&bbox[k], lo[k]); atomicMax(&bbox[7 + k], hi[k]); }
-        if (anybad) atomicOr(&bbox[14], 1u);
+        for (int k = 0; k < 7; ++k) { red[w][k] = lo[k]; red[w][7 + k] = hi[k]; }
+        red[w][14] = anybad ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 15u) {
+        const uint32_t k = threadIdx.x;
+        uint32_t v = red[0][k];
+        for (int ww = 1; ww < 4; ++ww) v = k < 7u ? min(v, red[ww][k]) : k < 14u ? max(v, red[ww][k]) : (v | red[ww][k]);
+        if (k < 7u) atomicMin(&bbox[k], v); else if (k < 14u) atomicMax(&bbox[k], v); else if (v) atomicOr(&bbox[14], 1u);
     }
 }
 
 hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa, uint32_t* bbox) {
     if (n == 0) return hipSuccess;
-    k_soa_repack<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox);
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
+    k_soa_repack<<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox);
     return hipGetLastError();
 }
 

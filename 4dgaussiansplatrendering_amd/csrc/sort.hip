@@ -418,8 +418,10 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
             const uint32_t k = skeys[l];
             const uint32_t d = ((k - bias) >> shift) & 255u;
             const uint32_t o = gpos[d] + (l - loff[d]);
-            keys_out[o] = k;
-            vals_out[o] = svals[l];
+            // streaming stores: the runs go to memory as they are written instead of sitting dirty in this XCD's L2 until the
+            // end-of-kernel write-back (the next pass reads them from other XCDs anyway)
+            __builtin_nontemporal_store(k, keys_out + o);
+            __builtin_nontemporal_store(svals[l], vals_out + o);
         }
     }
     if (stamps && tid == 0) stamps[tile * 8 + 5] = wall_clock64();

@@ -164,8 +164,8 @@ def main():
         # The dominant credited stage keeps its HIP events in the timed region.  A stage is `launches` launches of one kernel; achieved =
         # algorithmic bytes per launch / average launch duration (same ratio as stage bytes / stage time).  HBM traffic per launch comes
         # from the rocprofv3 --pmc passes of this very command committed under profiles/ (FETCH_SIZE doubled, KiB units; tools/pmc_traffic.py).
-        KERNEL = {"keygen": ("gs4d::k_keygen", 1), "sort": ("gs4d::k_os_pass", 4), "preprocess": ("gs4d::k_preprocess_4d", 1),
-                  "binning": ("gs4d::k_bin_emit", 1), "pairsort": ("gs4d::k_os_pass", 2), "composite": ("gs4d::k_composite<false>", 1)}
+        KERNEL = {"keygen": ("gs4d::k_keygen", 1), "sort": ("gs4d::k_os_pass", stats["depth_sort_passes"]), "preprocess": ("gs4d::k_preprocess_4d", 1),
+                  "binning": ("gs4d::k_bin_emit", 1), "pairsort": ("gs4d::k_os_pass", stats["tile_sort_passes"]), "composite": ("gs4d::k_composite<false>", 1)}
         roofline = None
         if timed:
             credited = max(timed, key=timed.get)
@@ -173,7 +173,7 @@ def main():
             ach = alg[credited] / (timed[credited] * 1e-3) / 1e9
             frame_ach = alg["frame"] / (ms_per_step * 1e-3) / 1e9
             traffic, tsrc = None, None
-            tfile = os.path.join(ROOT, "profiles", {1_000_000: "r01_b_pmc_traffic_c2.json", 10_000_000: "r01_b_pmc_traffic_c3.json"}.get(n, ""))
+            tfile = os.path.join(ROOT, "profiles", {1_000_000: "r01_c_pmc_traffic_c2.json", 10_000_000: "r01_c_pmc_traffic_c3.json"}.get(n, ""))
             if os.path.isfile(tfile):
                 pm = json.load(open(tfile))
                 hit = [v for k, v in pm.items() if k.startswith(kname)]
@@ -183,7 +183,7 @@ def main():
                         "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                         "traffic": traffic, "traffic_source": tsrc,
                         "kernel_ms": round(timed[credited] / launches, 5), "algorithmic_bytes_per_launch": alg[credited] // launches,
-                        "note": "order, preprocess and raster stages of consecutive frames overlap on three HIP streams: a launch timed in the pipeline is longer than the same launch alone (profiles/)",
+                        "note": "consecutive frames overlap on the device (frame lanes, one HIP stream each): a launch timed here runs beside the other lane's kernels and is longer than the same launch alone (profiles/README.md lists both)",
                         "slowest_stage": dom,
                         "frame": {"achieved": round(frame_ach, 2), "frac": round(frame_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": alg["frame"]},
                         "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
@@ -195,9 +195,9 @@ def main():
             "value": value, "unit": "splats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("1,000,000 random 3D splats in a 400^3 cube, single 1080p frame (BASELINE.json configs[1])" if not multi else
+            "config": {"workload": (f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else "") if not multi else
                                     "1,000,000 4D splats, time sweep, one 1080p frame per rank per step, RGBA8 frames gathered on rank 0 (BASELINE.json configs[3] shape)"),
-                       "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": world,
+                       "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": world, "frame_lanes": stats["lanes"],
                        "tile_list_entries": stats["entries"], "overflow_reruns": stats["reruns"]},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -9,5 +9,11 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 benc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 bench.py --splats $n --steps $steps --warmup $warm --no-cpu-baseline > $out/pmc_write.log 2>&1
 python3 tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $frames $out/pmc_traffic.json > $out/pmc_traffic.txt 2>&1
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
+# the same kernels running alone (one lane: nothing overlaps): what each launch costs by itself
+export GS4D_LANES=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace1 -- python3 bench.py --splats $n --steps $steps --warmup $warm --no-cpu-baseline --no-stage-events > $out/trace1.log 2>&1
+unset GS4D_LANES
+cp $(ls $out/trace1/*/*kernel_stats.csv | head -1) $out/kernel_stats_alone.csv
+rm -rf $out/trace1
 rm -rf $out/trace $out/pmc_fetch $out/pmc_write
 tail -c 600 $out/bench.json; echo; cat $out/pmc_traffic.txt
