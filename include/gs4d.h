@@ -13,7 +13,11 @@
  * Matrices are 16 floats, column-major (m[4*c + r]), exactly what glUniformMatrix4fv(…, GL_FALSE, …)
  * receives from glm::mat4.  Buffers are named by small integers like GL buffer names; 0 is "none";
  * deleting 0 or an already-deleted name is tolerated (the reference double-deletes, Scenes.h:220-224, 291-299).
- * Calls are issued in order on one HIP stream per context; only the read-back / finish calls block.
+ * Calls return as soon as their work is queued; only the read-back / finish calls block.  Results are as if the calls had run one
+ * after another.  Internally a context spreads consecutive FRAMES over a few HIP streams ("frame lanes", 2 by default) so that they
+ * overlap on the device: a frame is everything from one gs4d_clear / gs4d_keygen / gs4d_sort_pairs that follows a draw up to and
+ * including the next draw(s); buffers and the framebuffer carry their own cross-lane ordering.  A gs4d_clear starts rendering into the
+ * next image of a small swap chain (one RGBA32F image per lane); gs4d_read_pixels* read the image the last clear/draw used.
  * One context = one GPU; contexts are independent (one process per GPU for multi-GPU runs).
  * The framebuffer is RGBA float32, row 0 = bottom row (OpenGL window origin).
  */
@@ -102,20 +106,22 @@ GS4D_API int gs4d_draw_quads(gs4d_ctx* ctx, gs4d_buf vertices, size_t nquads);
 
 /* ---- read-back (no reference counterpart: the reference never reads its framebuffer) ---- */
 GS4D_API int gs4d_read_pixels(gs4d_ctx* ctx, float* rgba, size_t bytes);          /* blocking; bytes == width*height*16     */
-GS4D_API int gs4d_read_pixels_device(gs4d_ctx* ctx, void* dptr, size_t bytes);    /* device-to-device on the context stream; call gs4d_finish before using dptr on another stream */
+GS4D_API int gs4d_read_pixels_device(gs4d_ctx* ctx, void* dptr, size_t bytes);    /* device-to-device, asynchronous: ordered into the caller's stream if one was given (gs4d_set_stream), else call gs4d_finish before using dptr */
 /* Presentation format of the reference's window framebuffer (RGBA8 unorm, Application.cpp:89): clamp to [0,1], round to nearest.
- * Device-to-device on the context stream, width*height*4 bytes. */
+ * Device-to-device, asynchronous like gs4d_read_pixels_device, width*height*4 bytes. */
 GS4D_API int gs4d_read_pixels_rgba8_device(gs4d_ctx* ctx, void* dptr, size_t bytes);
-/* Run this context's work on a caller-owned HIP stream (hipStream_t passed as void*; NULL restores the context's own stream).
- * Lets a host framework order its own work (e.g. an RCCL gather of the frames) after the draw without a host synchronisation. */
+/* Name the caller's HIP stream (hipStream_t passed as void*; NULL: none).  The library keeps running on its own streams, but from now
+ * on (a) whatever the caller queued on that stream before an enqueueing call (keygen, sort, draw, device read-back) happens before the
+ * work of that call — e.g. a kernel of the caller's that fills a buffer obtained with gs4d_buffer_device_ptr — and (b) whatever the
+ * caller queues on it after a device read-back sees the pixels — e.g. an RCCL gather of the frames.  No host synchronisation. */
 GS4D_API int gs4d_set_stream(gs4d_ctx* ctx, void* hip_stream);
-GS4D_API int gs4d_finish(gs4d_ctx* ctx);                                          /* hipStreamSynchronize                   */
+GS4D_API int gs4d_finish(gs4d_ctx* ctx);                                          /* blocks until every lane is idle; reports device-side check failures */
 
 /* ---- measurement / test hooks ---- */
 GS4D_API int gs4d_set_profiling(gs4d_ctx* ctx, int stage_mask);                   /* bit (1 << GS4D_T_x) times stage x; 0 = off, 0x3F = every stage; each timed stage costs two event records per frame */
 GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);             /* blocking; -1.0f for stages that did not run */
 /* Start and end of every timed stage of the frames recorded so far (at most 128), in ms since the first timed stage of frame 0:
- * ms[frame][stage][2].  Shows how the three streams overlap.  Blocking; does not restart the ring (gs4d_get_timings does). */
+ * ms[frame][stage][2].  Shows how consecutive frames overlap.  Blocking; does not restart the ring (gs4d_get_timings does). */
 GS4D_API int gs4d_get_timeline(gs4d_ctx* ctx, float* ms, int max_frames, int* frames);
 GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[8]);                    /* [0] tile-list entries of the last draw, [1] capacity, [2] re-runs after overflow, [3] tiles,
                                                                                       [4] radix passes launched by the last gs4d_sort_pairs, [5] by the last draw's tile sort, [6] frame lanes, [7] 0 */
