@@ -73,7 +73,12 @@ def _load():
         "gs4d_host_build_records_4d": (None, [sz, vp, vp, vp, vp, vp, vp, vp, vp]),
         "gs4d_host_scene_linear": (None, [sz, vp, i32, f32, f32, vp, f32, f32, f32, vp]),
         "gs4d_host_scene_nonlinear": (None, [sz, vp, i32, f32, f32, f32, vp, f32, f32, f32, sz, vp]),
+        "gs4d_host_scene_rotation": (None, [sz, vp, i32, f32, f32, vp, f32, f32, f32, sz, vp]),
+        "gs4d_host_scene_combined": (None, [sz, vp, i32, f32, f32, f32, f32, f32, vp, f32, f32, f32, sz, vp]),
+        "gs4d_host_scene_broken": (None, [sz, vp, i32, f32, vp, f32, f32, f32, sz, vp]),
+        "gs4d_host_scene_square": (None, [sz, vp, i32, f32, f32, vp, f32, f32, f32, sz, vp]),
         "gs4d_host_parse_vdata": (C.c_long, [C.c_char_p, vp, sz]),
+        "gs4d_host_parse_sd": (C.c_long, [C.c_char_p, f32, vp, sz]),
         "gs4d_version": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
@@ -167,6 +172,42 @@ def scene_nonlinear(verts6, steps=92, angle_multiplier=4.0, radius=20.0, object_
     return rec
 
 
+def _scene_out(verts6, steps, max_records):
+    v = _f32(verts6).reshape(-1, 6)
+    n = v.shape[0] * steps if max_records is None else min(max_records, v.shape[0] * steps)
+    return v, n, np.empty((n, 24), np.float32)
+
+
+def scene_rotation(verts6, steps=92, angle_multiplier=4.0, object_scale=5.0, splat_scale=(4.0, 4.0, 1.0), lifetime=0.6, fade=0.5, speed=5.0, max_records=None):
+    """RotationMotion::init records (Scenes.h:775-803) with the class defaults (Scenes.h:711-727).  Camera (0,60,30) / (0,-1,-0.5)."""
+    v, n, rec = _scene_out(verts6, steps, max_records)
+    _lib.gs4d_host_scene_rotation(v.shape[0], _ptr(v), steps, angle_multiplier, object_scale, _ptr(_f32(splat_scale)), lifetime, fade, speed, n, _ptr(rec))
+    return rec
+
+
+def scene_combined(verts6, steps=65, angle_multiplier=8.0, lin_multiplier=8.0, amplitude=1.0, frequency=0.15, object_scale=5.0, splat_scale=(4.0, 4.0, 0.0),
+                   lifetime=1.0, fade=0.5, speed=1.0, max_records=None):
+    """CombinedMotion::init records (Scenes.h:1035-1068) with the class defaults (Scenes.h:959-976).  Camera (50,90,90) / (0,-1,-1)."""
+    v, n, rec = _scene_out(verts6, steps, max_records)
+    _lib.gs4d_host_scene_combined(v.shape[0], _ptr(v), steps, angle_multiplier, lin_multiplier, amplitude, frequency, object_scale, _ptr(_f32(splat_scale)),
+                                  lifetime, fade, speed, n, _ptr(rec))
+    return rec
+
+
+def scene_broken(verts6, steps=92, object_scale=5.0, splat_scale=(4.0, 4.0, 1.0), lifetime=1.0, fade=0.5, speed=1.0, max_records=None):
+    """BrokenMotion::init records (Scenes.h:1965-1989) with the class defaults (Scenes.h:1899-1912).  Camera (0,60,60) / (0,-1,-1)."""
+    v, n, rec = _scene_out(verts6, steps, max_records)
+    _lib.gs4d_host_scene_broken(v.shape[0], _ptr(v), steps, object_scale, _ptr(_f32(splat_scale)), lifetime, fade, speed, n, _ptr(rec))
+    return rec
+
+
+def scene_square(verts6, steps=92, square_size=40.0, object_scale=5.0, splat_scale=(4.0, 4.0, 1.0), lifetime=1.0, fade=0.5, speed=1.0, max_records=None):
+    """SquareMotion::init records (Scenes.h:2216-2259) with the class defaults (Scenes.h:2151-2165).  Camera (0,60,60) / (0,-1,-1)."""
+    v, n, rec = _scene_out(verts6, steps, max_records)
+    _lib.gs4d_host_scene_square(v.shape[0], _ptr(v), steps, square_size, object_scale, _ptr(_f32(splat_scale)), lifetime, fade, speed, n, _ptr(rec))
+    return rec
+
+
 def parse_vdata(path, cap_vertices=1 << 20):
     buf = np.empty((cap_vertices, 6), np.float32)
     n = _lib.gs4d_host_parse_vdata(os.fsencode(path), _ptr(buf), cap_vertices)
@@ -175,9 +216,18 @@ def parse_vdata(path, cap_vertices=1 << 20):
     return buf[:min(n, cap_vertices)].copy()
 
 
+def parse_sd(path, object_scale=1.0, cap_records=1 << 22):
+    """`.sd` splat file -> (n, 24) records (VDataParser.h:60-123 + ObjectDisplay::init, Scenes.h:2483-2491; its object scale defaults to 1)."""
+    buf = np.empty((cap_records, 24), np.float32)
+    n = _lib.gs4d_host_parse_sd(os.fsencode(path), object_scale, _ptr(buf), cap_records)
+    if n < 0:
+        raise FileNotFoundError(path)
+    return buf[:min(n, cap_records)].copy()
+
+
 # ---- device context -----------------------------------------------------------------------------
 class Context:
-    """One GPU, one HIP stream, one RGBA32F framebuffer (gs4d_ctx)."""
+    """One GPU context (gs4d_ctx): buffers, pipeline state, a small swap chain of RGBA32F framebuffers (one per frame lane)."""
 
     def __init__(self, width, height, device=0):
         h = C.c_void_p()

@@ -214,8 +214,8 @@ void get_color(const float pos[3], const Extrema& e, const float nrm[3], float o
     for (int k = 0; k < 3; ++k) out[k] = clamp01(lerpu(lower, max_bright, ((pos[k] - e.mn[k]) / (e.mx[k] - e.mn[k]))));
     out[3] = clamp01(1.0f);
 }
-// vec3(glm::rotate(vec4(1,0,0,0), angle, vec3(0,1,0)))  (gtx/rotate_vector.inl:66-74 -> ext/matrix_transform.inl:18-46)
-void rotate_forward_about_y(float angle, float out[3]) {
+// vec3(glm::rotate(vec4(v, 0), angle, vec3(0,1,0)))  (gtx/rotate_vector.inl:66-74 -> gtx/transform -> ext/matrix_transform.inl:18-46)
+void rotate_about_y(const float v3[3], float angle, float out[3]) {
     const float c = std::cos(angle), s = std::sin(angle);
     const float inv = 1.0f / std::sqrt((0.0f * 0.0f + 1.0f * 1.0f) + 0.0f * 0.0f);
     const float ax[3] = { 0.0f * inv, 1.0f * inv, 0.0f * inv };
@@ -231,8 +231,22 @@ void rotate_forward_about_y(float angle, float out[3]) {
         M[cc][r] = (i0 * Rm[cc][0] + i1 * Rm[cc][1]) + i2 * Rm[cc][2];
     }
     for (int r = 0; r < 4; ++r) M[3][r] = r == 3 ? 1.0f : 0.0f;
-    const float v[4] = { 1.0f, 0.0f, 0.0f, 0.0f };
+    const float v[4] = { v3[0], v3[1], v3[2], 0.0f };
     for (int r = 0; r < 3; ++r) out[r] = (M[0][r] * v[0] + M[1][r] * v[1]) + (M[2][r] * v[2] + M[3][r] * v[3]);     // mat4*vec4: (Mul0+Mul1)+(Mul2+Mul3)
+}
+void rotate_forward_about_y(float angle, float out[3]) { const float fwd[3] = { 1.0f, 0.0f, 0.0f }; rotate_about_y(fwd, angle, out); }
+
+constexpr float RAD = 0.01745329251994329576923690768489f;      // glm::radians
+
+// One record from (position, time, facing normal, velocity, colour inputs): the tail every scene loop shares
+// (Splat4D ctor Splat.h:132-159; quatLookAt + normalize; GetColor Scenes.h:58-68)
+void make_record(const float pos[3], float t, const float face_normal[3], const float splat_scale[3], float lifetime, float fade, const float vel[3],
+                 const float col_pos[3], const Extrema& e, const float col_normal[3], float* rec) {
+    const float up[3] = { 0.0f, 1.0f, 0.0f };
+    rec[0] = pos[0]; rec[1] = pos[1]; rec[2] = pos[2]; rec[3] = t;
+    get_color(col_pos, e, col_normal, rec + 4);
+    float q[4]; gs4d_host_quat_look_at(face_normal, up, q);
+    gs4d_host_splat4d_cov(q, splat_scale, lifetime, fade, vel, rec + 8);
 }
 
 } // namespace
@@ -261,7 +275,6 @@ void gs4d_host_scene_nonlinear(size_t nverts, const float* verts6, int steps, fl
                                const float splat_scale[3], float lifetime, float fade, float speed, size_t max_records, float* records24) {
     const Extrema e = extrema(verts6, nverts);
     const float up[3] = { 0.0f, 1.0f, 0.0f };
-    const float RAD = 0.01745329251994329576923690768489f;
     size_t o = 0;
     for (int dt = 0; dt < steps && o < max_records; ++dt) {
         float cur[3], nxt[3];
@@ -280,6 +293,93 @@ void gs4d_host_scene_nonlinear(size_t nverts, const float* verts6, int steps, fl
     }
 }
 
+// RotationMotion::init (Scenes.h:775-803): every vertex and its normal turn about the Y axis, 'angle_multiplier' degrees per time step.
+void gs4d_host_scene_rotation(size_t nverts, const float* verts6, int steps, float angle_multiplier, float object_scale, const float splat_scale[3],
+                              float lifetime, float fade, float speed, size_t max_records, float* records24) {
+    const Extrema e = extrema(verts6, nverts);
+    size_t o = 0;
+    for (int dt = 0; dt < steps && o < max_records; ++dt) {
+        const float a0 = float(dt * angle_multiplier) * RAD, a1 = float((dt + 1) * angle_multiplier) * RAD;
+        for (size_t i = 0; i < nverts && o < max_records; ++i, ++o) {
+            const float* pos = verts6 + 6 * i; const float* nrm = pos + 3;
+            float cur[3], nxt[3], nr[3];
+            rotate_about_y(pos, a0, cur); rotate_about_y(pos, a1, nxt); rotate_about_y(nrm, a0, nr);
+            const float p[3] = { object_scale * cur[0], object_scale * cur[1], object_scale * cur[2] };
+            const float vel[3] = { (nxt[0] - cur[0]) * speed, (nxt[1] - cur[1]) * speed, (nxt[2] - cur[2]) * speed };
+            make_record(p, float(dt), nr, splat_scale, lifetime, fade, vel, pos, e, nrm, records24 + 24 * o);
+        }
+    }
+}
+
+// CombinedMotion::init (Scenes.h:1035-1068): rotation about Y plus a sine-wave translation along X.
+void gs4d_host_scene_combined(size_t nverts, const float* verts6, int steps, float angle_multiplier, float lin_multiplier, float amplitude, float frequency,
+                              float object_scale, const float splat_scale[3], float lifetime, float fade, float speed, size_t max_records, float* records24) {
+    const Extrema e = extrema(verts6, nverts);
+    size_t o = 0;
+    for (int dt = 0; dt < steps && o < max_records; ++dt) {
+        const float a0 = float(dt * angle_multiplier) * RAD, a1 = float((dt + 1) * angle_multiplier) * RAD;
+        const float w0[3] = { lin_multiplier * (frequency * float(dt)), lin_multiplier * (amplitude * sinf(frequency * float(dt))), lin_multiplier * 0.0f };
+        const float w1[3] = { lin_multiplier * (frequency * float(dt + 1)), lin_multiplier * (amplitude * sinf(frequency * float(dt + 1))), lin_multiplier * 0.0f };
+        for (size_t i = 0; i < nverts && o < max_records; ++i, ++o) {
+            const float* pos = verts6 + 6 * i; const float* nrm = pos + 3;
+            const float md[3] = { object_scale * pos[0], object_scale * pos[1], object_scale * pos[2] };
+            float r0[3], r1[3], nr[3];
+            rotate_about_y(md, a0, r0); rotate_about_y(md, a1, r1); rotate_about_y(nrm, a0, nr);
+            const float p[3] = { r0[0] + w0[0], r0[1] + w0[1], r0[2] + w0[2] };
+            const float pn[3] = { r1[0] + w1[0], r1[1] + w1[1], r1[2] + w1[2] };
+            const float vel[3] = { (pn[0] - p[0]) * speed, (pn[1] - p[1]) * speed, (pn[2] - p[2]) * speed };
+            make_record(p, float(dt), nr, splat_scale, lifetime, fade, vel, pos, e, nrm, records24 + 24 * o);
+        }
+    }
+}
+
+// BrokenMotion::init (Scenes.h:1965-1989): the object jumps back every 20 steps (y = fmod(1 + dt, 20)).
+void gs4d_host_scene_broken(size_t nverts, const float* verts6, int steps, float object_scale, const float splat_scale[3],
+                            float lifetime, float fade, float speed, size_t max_records, float* records24) {
+    const Extrema e = extrema(verts6, nverts);
+    size_t o = 0;
+    for (int dt = 0; dt < steps && o < max_records; ++dt) {
+        const float pd[3] = { 1.0f + dt, std::fmod((1.0f + dt), 20.0f), 0.0f };
+        const float pn[3] = { 1.0f + (dt + 1.0f), std::fmod((1.0f + (dt + 1.0f)), 20.0f), 0.0f };
+        const float vel[3] = { (pn[0] - pd[0]) * speed, (pn[1] - pd[1]) * speed, (pn[2] - pd[2]) * speed };
+        for (size_t i = 0; i < nverts && o < max_records; ++i, ++o) {
+            const float* pos = verts6 + 6 * i; const float* nrm = pos + 3;
+            const float p[3] = { (object_scale * pos[0]) + pd[0], (object_scale * pos[1]) + pd[1], (object_scale * pos[2]) + pd[2] };
+            make_record(p, float(dt), nrm, splat_scale, lifetime, fade, vel, pos, e, nrm, records24 + 24 * o);
+        }
+    }
+}
+
+// SquareMotion::init (Scenes.h:2216-2259): the object walks the sides of a square in the XZ plane, steps/4 steps per side.
+void gs4d_host_scene_square(size_t nverts, const float* verts6, int steps, float square_size, float object_scale, const float splat_scale[3],
+                            float lifetime, float fade, float speed, size_t max_records, float* records24) {
+    const Extrema e = extrema(verts6, nverts);
+    size_t o = 0;
+    int side = 0;
+    const int per_side = steps / 4;
+    if (per_side <= 0) return;                               // the reference divides by zero here (Scenes.h:2219-2220)
+    const float delta = square_size / float(per_side);
+    float pd[3] = { square_size / 2.0f, 0.0f, square_size / 2.0f };
+    float pn[3] = { square_size / 2.0f + (delta * -1.0f), 0.0f + (delta * 0.0f), square_size / 2.0f + (delta * 0.0f) };
+    static const float DIRS[4][3] = { { -1.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, -1.0f }, { 1.0f, 0.0f, 0.0f }, { 0.0f, 0.0f, 1.0f } };
+    for (int dt = 0; dt < steps && o < max_records; ++dt) {
+        float dir[3] = { 0.0f, 0.0f, 0.0f };
+        if (dt > 0 && dt % per_side == 0) side += 1;
+        if (side >= 0 && side < 4) for (int k = 0; k < 3; ++k) dir[k] = DIRS[side][k];
+        for (int k = 0; k < 3; ++k) pd[k] = pd[k] + (delta * dir[k]);
+        int s2 = side;
+        if ((dt + 1) > 0 && (dt + 1) % per_side == 0) s2 += 1;
+        if (s2 >= 0 && s2 < 4) for (int k = 0; k < 3; ++k) dir[k] = DIRS[s2][k];       // s2 == 4 keeps the direction of `side`
+        for (int k = 0; k < 3; ++k) pn[k] = pn[k] + (delta * dir[k]);
+        const float vel[3] = { (pn[0] - pd[0]) * speed, (pn[1] - pd[1]) * speed, (pn[2] - pd[2]) * speed };
+        for (size_t i = 0; i < nverts && o < max_records; ++i, ++o) {
+            const float* pos = verts6 + 6 * i; const float* nrm = pos + 3;
+            const float p[3] = { (object_scale * pos[0]) + pd[0], (object_scale * pos[1]) + pd[1], (object_scale * pos[2]) + pd[2] };
+            make_record(p, float(dt), nrm, splat_scale, lifetime, fade, vel, pos, e, nrm, records24 + 24 * o);
+        }
+    }
+}
+
 // VData::parse (VDataParser.h:25-58): whitespace-separated std::stof tokens, 6 per vertex (position, normal).
 // Returns the number of vertices in the file (which may exceed cap_vertices; only cap_vertices are written), or -1 if it cannot be opened.
 long gs4d_host_parse_vdata(const char* path, float* verts6, size_t cap_vertices) {
@@ -289,6 +389,26 @@ long gs4d_host_parse_vdata(const char* path, float* verts6, size_t cap_vertices)
     while (file >> word) vals.push_back(std::stof(word));
     const size_t n = vals.size() / 6;
     for (size_t i = 0; i < n && i < cap_vertices; ++i) std::memcpy(verts6 + 6 * i, vals.data() + 6 * i, 24);
+    return (long)n;
+}
+
+// VData::parse_splat_data (VDataParser.h:60-123) followed by the ObjectDisplay record loop (Scenes.h:2483-2491): whitespace-separated
+// std::stof tokens, 23 per splat — position(3), colour(4), 4x4 covariance column by column(16) — become 96-byte records
+// {object_scale * position, 0 | colour | covariance}.  Returns the number of splats in the file (which may exceed cap_records; only
+// cap_records are written), or -1 if it cannot be opened.  A trailing partial splat is ignored (the reference reads past the end there).
+long gs4d_host_parse_sd(const char* path, float object_scale, float* records24, size_t cap_records) {
+    std::ifstream file(path);
+    if (!file.is_open()) return -1;
+    std::vector<float> vals; std::string word;
+    while (file >> word) vals.push_back(std::stof(word));
+    const size_t n = vals.size() / 23;
+    for (size_t i = 0; i < n && i < cap_records; ++i) {
+        const float* w = vals.data() + 23 * i;
+        float* rec = records24 + 24 * i;
+        rec[0] = object_scale * w[0]; rec[1] = object_scale * w[1]; rec[2] = object_scale * w[2]; rec[3] = 0.0f;
+        std::memcpy(rec + 4, w + 3, 16);
+        std::memcpy(rec + 8, w + 7, 64);
+    }
     return (long)n;
 }
 

@@ -148,7 +148,18 @@ GS4D_API void gs4d_host_scene_linear(size_t nverts, const float* verts6, int ste
                                      float lifetime, float fade, float speed, float* records24);                      /* Scenes.h:258-279, defaults :186-201 */
 GS4D_API void gs4d_host_scene_nonlinear(size_t nverts, const float* verts6, int steps, float angle_multiplier, float radius, float object_scale,
                                         const float splat_scale[3], float lifetime, float fade, float speed, size_t max_records, float* records24); /* Scenes.h:517-545, defaults :451-467 */
+GS4D_API void gs4d_host_scene_rotation(size_t nverts, const float* verts6, int steps, float angle_multiplier, float object_scale, const float splat_scale[3],
+                                       float lifetime, float fade, float speed, size_t max_records, float* records24);  /* Scenes.h:775-803, defaults :711-727 */
+GS4D_API void gs4d_host_scene_combined(size_t nverts, const float* verts6, int steps, float angle_multiplier, float lin_multiplier, float amplitude, float frequency,
+                                       float object_scale, const float splat_scale[3], float lifetime, float fade, float speed, size_t max_records,
+                                       float* records24);                                                               /* Scenes.h:1035-1068, defaults :959-976 */
+GS4D_API void gs4d_host_scene_broken(size_t nverts, const float* verts6, int steps, float object_scale, const float splat_scale[3],
+                                     float lifetime, float fade, float speed, size_t max_records, float* records24);    /* Scenes.h:1965-1989, defaults :1899-1912 */
+GS4D_API void gs4d_host_scene_square(size_t nverts, const float* verts6, int steps, float square_size, float object_scale, const float splat_scale[3],
+                                     float lifetime, float fade, float speed, size_t max_records, float* records24);    /* Scenes.h:2216-2259, defaults :2151-2165 */
 GS4D_API long gs4d_host_parse_vdata(const char* path, float* verts6, size_t cap_vertices);                            /* VDataParser.h:25-58 */
+/* .sd splat files (23 numbers per splat) -> 96-byte records as ObjectDisplay::init builds them; returns the splat count or -1 */
+GS4D_API long gs4d_host_parse_sd(const char* path, float object_scale, float* records24, size_t cap_records);           /* VDataParser.h:60-123, Scenes.h:2483-2491 */
 
 GS4D_API const char* gs4d_version(void);
 

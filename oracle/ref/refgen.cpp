@@ -8,12 +8,13 @@
 //   Splat4D::Splat4D (both ctors)      4DSplatRendering/Splat.h:91-159
 //   Splat3D::Splat3D                   4DSplatRendering/Splat.h:334-344
 //   Camera::GetViewMatrix/GetProjMatrix 4DSplatRendering/Camera.cpp:50-58
-//   VData::parse                       4DSplatRendering/VDataParser.h:25-58
+//   VData::parse / parse_splat_data    4DSplatRendering/VDataParser.h:25-58, 60-123
 //   Scenes::GetModelExtrema/GetColor   4DSplatRendering/Scenes.h:58-91   (+ Utils.cpp lerp/mapf/minf/maxf)
 //   Scenes::SplatData::GetMeanInTime   4DSplatRendering/Scenes.h:28-36
 //   glm::quatLookAt / normalize / rotate (vendored GLM 0.9.9.9)
 // What this harness restates itself (loops only, no arithmetic of its own): the per-splat generation loops of
-// LinearMotion::init (Scenes.h:258-279) and NonLinearMotion::init (Scenes.h:517-545) and the key loop
+// LinearMotion::init (Scenes.h:258-279), NonLinearMotion (:517-545), RotationMotion (:775-803), CombinedMotion (:1035-1068),
+// BrokenMotion (:1965-1989), SquareMotion (:2216-2259) and the key loop
 // (Scenes.h:314-319), because those bodies sit inside methods that also call OpenGL.
 // Not buildable here, therefore not used: anything that needs an OpenGL context or GLEW/GLFW/ImGui
 // libraries (Renderer.cpp, Shader.cpp, the scene classes' init/Render, radix_sort.hpp) and all GLSL.
@@ -244,6 +245,135 @@ int main(int argc, char** argv) {
         dump("nonlinear_first500", "f32", nl.data(), 500 * 24, 24);
         dump("nonlinear_block45_first200", "f32", nl.data() + 45 * model.size(), 200 * 24, 24);
         char buf[128]; snprintf(buf, sizeof buf, "{\"records\": %zu, \"crc32\": %u}", nl.size(), crc32_buf(nl.data(), nl.size() * 96)); note("nonlinear_full", buf);
+    }
+    // ---- (9) RotationMotion SSBO (Scenes.h:775-803) with the class defaults (Scenes.h:711-727)
+    {
+        const int steps = 92; const float oscale = 5.0f, sx = 4.0f, sy = 4.0f, sz = 1.0f, life = 0.6f, fade = 0.5f, speed = 5.0f, amul = 4.0f;
+        std::vector<Scenes::SplatData> sd;
+        ModelEdges medge = Scenes::GetModelExtrema(model);
+        for (int dt = 0; dt < steps; ++dt)
+            for (int i = 0; i < (int)model.size(); ++i) {
+                glm::vec4 pos{ model[i][0], 0.0 };
+                glm::vec3 timeOffset = glm::vec3{ glm::rotate(pos, glm::radians(float(dt * amul)), { 0.0, 1.0, 0.0 }) };
+                glm::vec3 timeOffset_next = glm::vec3{ glm::rotate(pos, glm::radians(float((dt + 1) * amul)), { 0.0, 1.0, 0.0 }) };
+                glm::vec3 norm = glm::vec3{ glm::rotate(glm::vec4{ model[i][1], 0 }, glm::radians(float(dt * amul)), { 0.0, 1.0, 0.0 }) };
+                Splat4D s4d{ glm::vec4{ (oscale * timeOffset), float(dt) },
+                             glm::normalize(glm::quatLookAt(glm::normalize(norm), glm::vec3(0, 1, 0))),
+                             glm::vec3{ sx, sy, sz }, life, fade, (timeOffset_next - timeOffset) * speed,
+                             Scenes::GetColor(pos, medge, model[i][1]) };
+                sd.push_back({ s4d.GetPosititon(), s4d.GetColor(), s4d.GetGeoInfo() });
+            }
+        dump("rotation_first300", "f32", sd.data(), 300 * 24, 24);
+        dump("rotation_block45_first200", "f32", sd.data() + 45 * model.size(), 200 * 24, 24);
+        char buf[128]; snprintf(buf, sizeof buf, "{\"records\": %zu, \"crc32\": %u}", sd.size(), crc32_buf(sd.data(), sd.size() * 96)); note("rotation_full", buf);
+    }
+    // ---- (10) CombinedMotion SSBO (Scenes.h:1035-1068) with the class defaults (Scenes.h:959-976)
+    {
+        const int steps = 65; const float oscale = 5.0f, sx = 4.0f, sy = 4.0f, sz = 0.0f, life = 1.0f, fade = 0.5f, speed = 1.0f, amul = 8.0f, lmul = 8.0f, amp = 1.0f, freq = 0.15f;
+        std::vector<Scenes::SplatData> sd;
+        ModelEdges medge = Scenes::GetModelExtrema(model);
+        for (int dt = 0; dt < steps; ++dt)
+            for (int i = 0; i < (int)model.size(); ++i) {
+                glm::vec3 md = oscale * model[i][0];
+                glm::vec3 nd = model[i][1];
+                glm::vec3 pos = glm::vec3{ glm::rotate(glm::vec4{ md, 0 }, glm::radians(float(dt * amul)), { 0.0, 1.0, 0.0 }) } + lmul * glm::vec3{ freq * float(dt), amp * sinf(freq * float(dt)), 0.0f };
+                glm::vec3 pos_next = glm::vec3{ glm::rotate(glm::vec4{ md, 0 }, glm::radians(float((dt + 1) * amul)), { 0.0, 1.0, 0.0 }) } + lmul * glm::vec3{ freq * float(dt + 1), amp * sinf(freq * float(dt + 1)), 0.0f };
+                glm::vec3 norm = glm::vec3{ glm::rotate(glm::vec4{ nd, 0 }, glm::radians(float(dt * amul)), { 0.0, 1.0, 0.0 }) };
+                Splat4D s4d{ glm::vec4{ pos, float(dt) },
+                             glm::normalize(glm::quatLookAt(glm::normalize(norm), glm::vec3(0, 1, 0))),
+                             glm::vec3{ sx, sy, sz }, life, fade, (pos_next - pos) * speed,
+                             Scenes::GetColor(model[i][0], medge, model[i][1]) };
+                sd.push_back({ s4d.GetPosititon(), s4d.GetColor(), s4d.GetGeoInfo() });
+            }
+        dump("combined_first300", "f32", sd.data(), 300 * 24, 24);
+        dump("combined_block33_first200", "f32", sd.data() + 33 * model.size(), 200 * 24, 24);
+        char buf[128]; snprintf(buf, sizeof buf, "{\"records\": %zu, \"crc32\": %u}", sd.size(), crc32_buf(sd.data(), sd.size() * 96)); note("combined_full", buf);
+    }
+    // ---- (11) BrokenMotion SSBO (Scenes.h:1965-1989) with the class defaults (Scenes.h:1899-1912)
+    {
+        const int steps = 92; const float oscale = 5.0f, sx = 4.0f, sy = 4.0f, sz = 1.0f, life = 1.0f, fade = 0.5f, speed = 1.0f;
+        std::vector<Scenes::SplatData> sd;
+        ModelEdges medge = Scenes::GetModelExtrema(model);
+        for (int dt = 0; dt < steps; ++dt) {
+            glm::vec3 posdt{ 1.0f + dt, fmod((1.0f + dt), 20.0f), 0.0f };
+            glm::vec3 posdtn{ 1.0f + (dt + 1.0f), fmod((1.0f + (dt + 1.0f)), 20.0f), 0.0f };
+            for (int i = 0; i < (int)model.size(); ++i) {
+                glm::vec3 pos = model[i][0];
+                Splat4D s4d{ glm::vec4{ (oscale * pos) + (posdt), float(dt) },
+                             glm::normalize(glm::quatLookAt(glm::normalize(model[i][1]), glm::vec3(0, 1, 0))),
+                             glm::vec3{ sx, sy, sz }, life, fade, (posdtn - posdt) * speed,
+                             Scenes::GetColor(pos, medge, model[i][1]) };
+                sd.push_back({ s4d.GetPosititon(), s4d.GetColor(), s4d.GetGeoInfo() });
+            }
+        }
+        dump("broken_first300", "f32", sd.data(), 300 * 24, 24);
+        dump("broken_block19_first200", "f32", sd.data() + 19 * model.size(), 200 * 24, 24);
+        char buf[128]; snprintf(buf, sizeof buf, "{\"records\": %zu, \"crc32\": %u}", sd.size(), crc32_buf(sd.data(), sd.size() * 96)); note("broken_full", buf);
+    }
+    // ---- (12) SquareMotion SSBO (Scenes.h:2216-2259) with the class defaults (Scenes.h:2151-2165)
+    {
+        const int steps = 92; const float oscale = 5.0f, sx = 4.0f, sy = 4.0f, sz = 1.0f, life = 1.0f, fade = 0.5f, speed = 1.0f, size = 40.0f;
+        std::vector<Scenes::SplatData> sd;
+        ModelEdges medge = Scenes::GetModelExtrema(model);
+        int side = 0;
+        int stepsPerSide = steps / 4;
+        float deltaStep = size / float(stepsPerSide);
+        glm::vec3 posdt{ size / 2.0f, 0.0, size / 2.0f };
+        glm::vec3 posdtn = glm::vec3{ size / 2.0f, 0.0, size / 2.0f } + (deltaStep * glm::vec3{ -1.0f, 0.0f, 0.0f });
+        for (int dt = 0; dt < steps; ++dt) {
+            glm::vec3 dir{ 0 };
+            if (dt > 0 && dt % stepsPerSide == 0) side += 1;
+            if (side == 0) dir = { -1.0f, 0.0f, 0.0f };
+            if (side == 1) dir = { 0.0f, 0.0f, -1.0f };
+            if (side == 2) dir = { 1.0f, 0.0f, 0.0f };
+            if (side == 3) dir = { 0.0f, 0.0f, 1.0f };
+            posdt = posdt + (deltaStep * dir);
+            int s2 = side;
+            if ((dt + 1) > 0 && (dt + 1) % stepsPerSide == 0) s2 += 1;
+            if (s2 == 0) dir = { -1.0f, 0.0f, 0.0f };
+            if (s2 == 1) dir = { 0.0f, 0.0f, -1.0f };
+            if (s2 == 2) dir = { 1.0f, 0.0f, 0.0f };
+            if (s2 == 3) dir = { 0.0f, 0.0f, 1.0f };
+            posdtn = posdtn + (deltaStep * dir);
+            for (int i = 0; i < (int)model.size(); ++i) {
+                glm::vec3 pos = model[i][0];
+                Splat4D s4d{ glm::vec4{ (oscale * pos) + (posdt), float(dt) },
+                             glm::normalize(glm::quatLookAt(glm::normalize(model[i][1]), glm::vec3(0, 1, 0))),
+                             glm::vec3{ sx, sy, sz }, life, fade, (posdtn - posdt) * speed,
+                             Scenes::GetColor(pos, medge, model[i][1]) };
+                sd.push_back({ s4d.GetPosititon(), s4d.GetColor(), s4d.GetGeoInfo() });
+            }
+        }
+        dump("square_first300", "f32", sd.data(), 300 * 24, 24);
+        dump("square_block23_first200", "f32", sd.data() + 23 * model.size(), 200 * 24, 24);
+        dump("square_block91_first200", "f32", sd.data() + 91 * model.size(), 200 * 24, 24);
+        char buf[128]; snprintf(buf, sizeof buf, "{\"records\": %zu, \"crc32\": %u}", sd.size(), crc32_buf(sd.data(), sd.size() * 96)); note("square_full", buf);
+    }
+    // ---- (13) VData::parse_splat_data (.sd, VDataParser.h:60-123) + the ObjectDisplay record loop (Scenes.h:2483-2491, object scale 2.5 here).
+    // The reference ships no .sd file: a small synthetic one is written next to the fixtures (data, 23 numbers per splat: position,
+    // colour, 4x4 covariance column by column) and read back through the reference's parser.
+    {
+        const std::string sd_path = g_out + "/synthetic.sd";
+        FILE* f = fopen(sd_path.c_str(), "w");
+        ModelEdges medge = Scenes::GetModelExtrema(model);
+        const int n = 48;
+        for (int i = 0; i < n; ++i) {
+            const int v = (i * 71) % (int)model.size();
+            glm::vec3 pos = model[v][0];
+            Splat4D s4d{ glm::vec4{ 5.0f * pos, float(i % 7) }, glm::normalize(glm::quatLookAt(glm::normalize(model[v][1]), glm::vec3(0, 1, 0))),
+                         glm::vec3{ 4.0f, 2.0f + 0.125f * float(i % 5), 1.0f }, 1.0f, 0.5f, glm::vec3{ 1.0f, 0.25f * float(i % 3), 0.0f },
+                         Scenes::GetColor(pos, medge, model[v][1]) };
+            glm::mat4 c = s4d.GetGeoInfo(); glm::vec4 col = s4d.GetColor();
+            fprintf(f, "%.9g %.9g %.9g  %.9g %.9g %.9g %.9g ", pos.x, pos.y, pos.z, col.x, col.y, col.z, col.w);
+            for (int cc = 0; cc < 4; ++cc) for (int r = 0; r < 4; ++r) fprintf(f, " %.9g", c[cc][r]);
+            fprintf(f, i % 2 ? "\n" : "\n\n");        // blank lines are skipped by the parser
+        }
+        fclose(f);
+        std::vector<VData::VSplatData> sd = VData::parse_splat_data(sd_path);
+        const float oscale = 2.5f;
+        std::vector<Scenes::SplatData> recs;
+        for (auto& m : sd) recs.push_back({ glm::vec4{ oscale * m.pos, 0.0 }, m.color, m.cov });
+        dump("synthetic_sd_records", "f32", recs.data(), recs.size() * 24, 24);
     }
     fprintf(g_manifest, "\n}\n"); fclose(g_manifest);
     printf("refgen: fixtures written to %s\n", g_out.c_str());

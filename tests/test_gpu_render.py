@@ -135,6 +135,41 @@ def test_nonlinear_teapot_4k(gs4d, oracle):
     ctx.close()
 
 
+@pytest.mark.parametrize("name,cam,t", [
+    ("rotation", ((0.0, 60.0, 30.0), (0.0, -1.0, -0.5)), 20.25),      # cameras: Scenes.h:748-749, 1003-1004, 1941-1942, 2192-2193
+    ("combined", ((50.0, 90.0, 90.0), (0.0, -1.0, -1.0)), 31.5),
+    ("broken", ((0.0, 60.0, 60.0), (0.0, -1.0, -1.0)), 19.75),        # just before the jump back (y = fmod(1 + dt, 20))
+    ("square", ((0.0, 60.0, 60.0), (0.0, -1.0, -1.0)), 23.0),         # at a corner of the square
+])
+def test_motion_scenes_render(gs4d, oracle, name, cam, t):
+    """The other four teapot scenes of the reference at their full size and their own cameras, one mid-sweep frame each, 1280x720,
+    sort on (the reference leaves m_DoSort off by default in some of them; the path is the same)."""
+    W, H = 1280, 720
+    ctx = gs4d.Context(W, H)
+    rec = getattr(gs4d, "scene_" + name)(oracle.golden("teapot_vdata"))
+    img, projd, _, (view, proj) = gpu_frame(ctx, gs4d, rec, cam, t=t)
+    eimg, _, _ = oracle.render_4d(rec, True, t, 0.0, cam[0], view, proj, W, H, nthreads=16)
+    check_projected(oracle, projd, oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, 0.0))
+    assert linf(img, eimg) <= TOL
+    assert np.abs(eimg - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.3
+    ctx.close()
+
+
+def test_object_display_from_sd_file(gs4d, oracle):
+    """ObjectDisplay (Scenes.h:2457-2500): records loaded from a .sd file, its camera (0,2,8) -> (0,-0.10,-1.4), sort on."""
+    import os
+    W, H = 1024, 576
+    ctx = gs4d.Context(W, H)
+    rec = gs4d.parse_sd(os.path.join(os.path.dirname(__file__), "golden", "synthetic.sd"), object_scale=1.0)
+    cam = ((0.0, 2.0, 8.0), (0.0, -0.10, -1.4))
+    img, projd, _, (view, proj) = gpu_frame(ctx, gs4d, rec, cam, t=0.0)
+    eimg, _, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    check_projected(oracle, projd, oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, 0.0, 0.0))
+    assert linf(img, eimg) <= TOL
+    assert np.abs(eimg - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.05
+    ctx.close()
+
+
 def test_time_sweep_1e6_4d_splats(ctx1080, gs4d, oracle):
     """Config 4, one frame of the sweep at full size: 1e6 4D splats (velocity, lifetime, mu_t in [0,50]) at t = 50*100/255."""
     n = 1000000
