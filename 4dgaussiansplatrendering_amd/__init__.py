@@ -338,15 +338,16 @@ class Context:
         self._chk(_lib.gs4d_finish(self._h))
 
     # measurement
-    def set_profiling(self, on):
-        """False: off; True: every stage; an iterable of stage names: only those (each timed stage costs two event records per frame)."""
+    def set_profiling(self, on, every=1):
+        """False: off; True: every stage; an iterable of stage names: only those.  every=k: time only every k-th frame (each timed stage
+        costs two event records in a timed frame)."""
         if isinstance(on, (list, tuple, set)):
             mask = 0
             for name in on:
                 mask |= 1 << STAGES.index(name)
         else:
             mask = 0x3F if on else 0
-        self._chk(_lib.gs4d_set_profiling(self._h, mask))
+        self._chk(_lib.gs4d_set_profiling(self._h, mask | ((int(every) & 0xFF) << 8 if mask and every > 1 else 0)))
 
     def timings(self):
         ms = np.zeros(len(STAGES), np.float32)

@@ -106,6 +106,8 @@ struct gs4d_ctx {
     static constexpr int PROF_FRAMES = 128;
     unsigned profiling = 0;                    // bit s set: stage s is timed
     int prof_frame = 0;
+    int prof_every = 1;                        // only every prof_every-th frame is timed ...
+    uint64_t prof_tick = 0;                    // ... counted here (a frame ends with its draw)
     std::vector<hipEvent_t> ev0, ev1;          // [PROF_FRAMES][GS4D_T_COUNT], created on first use
     std::vector<uint8_t> ran;
 };
@@ -128,7 +130,7 @@ Lane& lane(gs4d_ctx* c) { return c->lanes[c->cur]; }
 struct StageTimer {
     gs4d_ctx* c; int slot; hipStream_t s;
     StageTimer(gs4d_ctx* c_, int id) : c(c_), slot(-1), s(c_->lanes[c_->cur].s) {
-        if (((c->profiling >> id) & 1u) && c->prof_frame < gs4d_ctx::PROF_FRAMES) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], s); }
+        if (((c->profiling >> id) & 1u) && c->prof_frame < gs4d_ctx::PROF_FRAMES && c->prof_tick % (uint64_t)c->prof_every == 0) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], s); }
     }
     ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(c->ev1[slot], s); c->ran[slot] = 1; } }
 };
@@ -667,7 +669,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     if (rc) { L.proj_n = before; return rc; }
     if (L.proj_n) { c->pending = true; c->pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; }   // proj_n != 0 <=> raster work was enqueued
     else L.proj_n = before;
-    if (c->profiling && c->prof_frame < gs4d_ctx::PROF_FRAMES) c->prof_frame++;
+    if (c->profiling) { if (c->prof_frame < gs4d_ctx::PROF_FRAMES && c->prof_tick % (uint64_t)c->prof_every == 0) c->prof_frame++; c->prof_tick++; }
     return GS4D_OK;
 }
 
@@ -760,6 +762,8 @@ int gs4d_set_profiling(gs4d_ctx* c, int stage_mask) {
         for (size_t i = 0; i < n; ++i) { HIPCHK(c, hipEventCreate(&c->ev0[i])); HIPCHK(c, hipEventCreate(&c->ev1[i])); }
     }
     c->profiling = (unsigned)stage_mask & 0x3Fu;
+    c->prof_every = ((stage_mask >> 8) & 0xFF) ? ((stage_mask >> 8) & 0xFF) : 1;
+    c->prof_tick = 0;
     c->prof_frame = 0;
     std::fill(c->ran.begin(), c->ran.end(), 0);
     return GS4D_OK;

@@ -118,7 +118,8 @@ GS4D_API int gs4d_set_stream(gs4d_ctx* ctx, void* hip_stream);
 GS4D_API int gs4d_finish(gs4d_ctx* ctx);                                          /* blocks until every lane is idle; reports device-side check failures */
 
 /* ---- measurement / test hooks ---- */
-GS4D_API int gs4d_set_profiling(gs4d_ctx* ctx, int stage_mask);                   /* bit (1 << GS4D_T_x) times stage x; 0 = off, 0x3F = every stage; each timed stage costs two event records per frame */
+GS4D_API int gs4d_set_profiling(gs4d_ctx* ctx, int stage_mask);                   /* bit (1 << GS4D_T_x) times stage x; 0 = off, 0x3F = every stage; bits 8..15 = k: time only every k-th frame (0 = every frame).
+                                                                                      Each timed stage costs two event records in a timed frame (they break back-to-back kernel dispatch: ~2 us each on the device) */
 GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);             /* blocking; -1.0f for stages that did not run */
 /* Start and end of every timed stage of the frames recorded so far (at most 128), in ms since the first timed stage of frame 0:
  * ms[frame][stage][2].  Shows how consecutive frames overlap.  Blocking; does not restart the ring (gs4d_get_timings does). */
