@@ -170,6 +170,40 @@ def test_object_display_from_sd_file(gs4d, oracle):
     ctx.close()
 
 
+def test_config5_full_size_10m_4d_splats_4k(gs4d, oracle):
+    """BASELINE.json configs[4] at its full size on one GPU: 10^7 4D splats from the NonLinearMotion generator (2745 time steps = four
+    laps of the circle), 3840x2160, t = 1372, sort on.  5.4e8 tile-list entries (the first frame overflows the
+    speculative capacity and is re-run).  Per-pixel diff against the CPU checker (~15 s on 64 host threads) and the permutation."""
+    import os
+    n, W, H, steps = 10_000_000, 3840, 2160, 2745
+    rec = gs4d.scene_nonlinear(oracle.golden("teapot_vdata"), steps=steps, angle_multiplier=360.0 / steps * 4.0, max_records=n)
+    assert rec.shape == (n, 24)
+    cam, t = scenes.CAM_NONLINEAR, 1372.0
+    view, proj = cam_mats(gs4d, cam, W, H)
+    ctx = gs4d.Context(W, H)
+    data, keys, idx = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.bind(2, data)
+    ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+    ctx.clear()
+    ctx.keygen(data, t, cam[0], keys, idx, n)
+    ctx.sort_pairs(keys, idx, n)
+    ctx.bind(1, idx)
+    ctx.draw_instanced(n)
+    img = ctx.read_pixels()
+    stats = ctx.stats()
+    perm = ctx.read(idx, np.uint32, n)
+    ctx.close()
+    eidx, ekeys = oracle.keygen(rec, t, cam[0])
+    _, eperm = oracle.sort_pairs(ekeys.view(np.uint32), eidx, "lsd")
+    assert np.array_equal(perm, eperm)
+    eimg, _, _ = oracle.render_4d(rec, True, t, 0.0, cam[0], view, proj, W, H, nthreads=min(os.cpu_count() or 8, 64))
+    assert linf(img, eimg) <= TOL
+    assert np.abs(eimg - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.3
+    assert stats["entries"] > 100_000_000 and stats["reruns"] >= 1
+
+
 def test_time_sweep_1e6_4d_splats(ctx1080, gs4d, oracle):
     """Config 4, one frame of the sweep at full size: 1e6 4D splats (velocity, lifetime, mu_t in [0,50]) at t = 50*100/255."""
     n = 1000000
