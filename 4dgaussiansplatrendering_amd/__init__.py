@@ -67,6 +67,9 @@ def _load():
         "gs4d_host_perspective": (None, [f32, i32, i32, f32, f32, vp]),
         "gs4d_host_quat_look_at": (None, [vp, vp, vp]),
         "gs4d_host_splat3d_cov": (None, [vp, vp, vp]),
+        "gs4d_host_splat3d_mesh": (None, [vp, vp, vp, vp, vp]),
+        "gs4d_host_splat2d_sigma_inv": (None, [vp, f32, f32, vp]),
+        "gs4d_host_gaussians2d_record": (None, [f32, f32, f32, f32, f32, vp, vp]),
         "gs4d_host_splat4d_cov": (None, [vp, vp, f32, f32, vp, vp]),
         "gs4d_host_splat4d_cov2q": (None, [vp, vp, vp, vp]),
         "gs4d_host_build_records_3d": (None, [sz, vp, vp, vp, vp, vp]),
@@ -214,6 +217,27 @@ def parse_vdata(path, cap_vertices=1 << 20):
     if n < 0:
         raise FileNotFoundError(path)
     return buf[:min(n, cap_vertices)].copy()
+
+
+def splat3d_mesh(pos3, q_wxyz, scale3, color4):
+    """Splat3D::GetSplatMesh (Splat.h:433-447): (4, 18) float32 = four 72-byte vertices {corner, position, colour, Sigma3}."""
+    out = np.empty((4, 18), np.float32)
+    _lib.gs4d_host_splat3d_mesh(_ptr(_f32(pos3)), _ptr(_f32(q_wxyz)), _ptr(_f32(scale3)), _ptr(_f32(color4)), _ptr(out))
+    return out
+
+
+def splat2d_sigma_inv(v0, l0, l1):
+    """Splat2D::CalcAndSetSigma (Splat.h:576-582): inverse 2x2 covariance, column-major."""
+    out = np.empty(4, np.float32)
+    _lib.gs4d_host_splat2d_sigma_inv(_ptr(_f32(v0)), l0, l1, _ptr(out))
+    return out
+
+
+def gaussians2d_record(angle, s0, s1, px, py, rgb):
+    """One 48-byte record of the Gaussians2D scene (Scenes.h:1490-1496) for GS4D_MODE_2D."""
+    out = np.empty(12, np.float32)
+    _lib.gs4d_host_gaussians2d_record(angle, s0, s1, px, py, _ptr(_f32(rgb)), _ptr(out))
+    return out
 
 
 def parse_sd(path, object_scale=1.0, cap_records=1 << 22):

@@ -136,6 +136,55 @@ void gs4d_host_splat3d_cov(const float q_wxyz[4], const float scale3[3], float c
     std::memcpy(cov9, g.a, sizeof g.a);
 }
 
+// Splat3D::GetSplatMesh / MakeMesh (Splat.h:433-473; vertex layout Geometry.h:37-42): the four 72-byte vertices of one splat's quad,
+// {corner(2), position(3), colour(4), Sigma3(9, column-major)}, corners in the order the index buffer 0,2,1 / 2,0,3 expects (Geometry.h:44-50).
+void gs4d_host_splat3d_mesh(const float pos3[3], const float q_wxyz[4], const float scale3[3], const float color4[4], float verts72[72]) {
+    float cov[9];
+    gs4d_host_splat3d_cov(q_wxyz, scale3, cov);
+    static const float corner[4][2] = { { 0.5f, 0.5f }, { 0.5f, -0.5f }, { -0.5f, -0.5f }, { -0.5f, 0.5f } };
+    for (int v = 0; v < 4; ++v) {
+        float* o = verts72 + 18 * v;
+        o[0] = corner[v][0]; o[1] = corner[v][1];
+        std::memcpy(o + 2, pos3, 12);
+        std::memcpy(o + 5, color4, 16);
+        std::memcpy(o + 9, cov, 36);
+    }
+}
+
+// Splat2D ctor + CalcAndSetSigma (Splat.h:551-582): Sigma^-1 of R S S^T R^T with R = (normalize(v0), normalize(v0.y, -v0.x)), S = diag(sqrt l0, sqrt l1)
+void gs4d_host_splat2d_sigma_inv(const float v0[2], float l0, float l1, float sigma_inv4[4]) {
+    const float s0 = sqrtf(l0), s1 = sqrtf(l1);
+    auto norm2 = [](float x, float y, float* o) { const float inv = 1.0f / std::sqrt(x * x + y * y); o[0] = x * inv; o[1] = y * inv; };   // glm::normalize = v * inversesqrt(dot(v, v))
+    float r0[2], r1[2];
+    norm2(v0[0], v0[1], r0);
+    norm2(v0[1], -v0[0], r1);
+    // column-major 2x2: m[c][r]; glm mat2 * mat2 (type_mat2x2.inl:453-460)
+    struct M2 { float m[2][2]; };
+    auto mul = [](const M2& a, const M2& b) { M2 c;
+        c.m[0][0] = a.m[0][0] * b.m[0][0] + a.m[1][0] * b.m[0][1]; c.m[0][1] = a.m[0][1] * b.m[0][0] + a.m[1][1] * b.m[0][1];
+        c.m[1][0] = a.m[0][0] * b.m[1][0] + a.m[1][0] * b.m[1][1]; c.m[1][1] = a.m[0][1] * b.m[1][0] + a.m[1][1] * b.m[1][1]; return c; };
+    auto tr = [](const M2& a) { M2 c; c.m[0][0] = a.m[0][0]; c.m[0][1] = a.m[1][0]; c.m[1][0] = a.m[0][1]; c.m[1][1] = a.m[1][1]; return c; };
+    const M2 S = { { { s0, 0.0f }, { 0.0f, s1 } } }, R = { { { r0[0], r0[1] }, { r1[0], r1[1] } } };
+    const M2 sig = mul(mul(mul(R, S), tr(S)), tr(R));
+    const float ood = 1.0f / (sig.m[0][0] * sig.m[1][1] - sig.m[1][0] * sig.m[0][1]);        // glm::inverse (func_matrix.inl:303-317)
+    sigma_inv4[0] = sig.m[1][1] * ood; sigma_inv4[1] = -sig.m[0][1] * ood; sigma_inv4[2] = -sig.m[1][0] * ood; sigma_inv4[3] = sig.m[0][0] * ood;
+}
+
+// One 48-byte record of the Gaussians2D scene (Scenes.h:1490-1496, struct :1447-1452): {x, y, 0, 0 | r, g, b, 1 | R S S R^T} with
+// R = {cosf a, -sinf a, sinf a, cos a} (`cos` on a float picks the float overload, here as under MSVC: the fixtures confirm it).
+void gs4d_host_gaussians2d_record(float angle, float s0, float s1, float px, float py, const float rgb[3], float rec12[12]) {
+    struct M2 { float m[2][2]; };
+    auto mul = [](const M2& a, const M2& b) { M2 c;
+        c.m[0][0] = a.m[0][0] * b.m[0][0] + a.m[1][0] * b.m[0][1]; c.m[0][1] = a.m[0][1] * b.m[0][0] + a.m[1][1] * b.m[0][1];
+        c.m[1][0] = a.m[0][0] * b.m[1][0] + a.m[1][0] * b.m[1][1]; c.m[1][1] = a.m[0][1] * b.m[1][0] + a.m[1][1] * b.m[1][1]; return c; };
+    auto tr = [](const M2& a) { M2 c; c.m[0][0] = a.m[0][0]; c.m[0][1] = a.m[1][0]; c.m[1][0] = a.m[0][1]; c.m[1][1] = a.m[1][1]; return c; };
+    const M2 R = { { { cosf(angle), -sinf(angle) }, { sinf(angle), std::cos(angle) } } }, S = { { { s0, 0.0f }, { 0.0f, s1 } } };
+    const M2 g = mul(mul(mul(R, S), S), tr(R));
+    rec12[0] = px; rec12[1] = py; rec12[2] = 0.0f; rec12[3] = 0.0f;
+    rec12[4] = rgb[0]; rec12[5] = rgb[1]; rec12[6] = rgb[2]; rec12[7] = 1.0f;
+    rec12[8] = g.m[0][0]; rec12[9] = g.m[0][1]; rec12[10] = g.m[1][0]; rec12[11] = g.m[1][1];
+}
+
 void gs4d_host_splat4d_cov(const float q_wxyz[4], const float scale3[3], float lifetime, float fade, const float dir[3], float cov16[16]) {
     // Splat.h:139: `log(fadeof)` on a float is the float overload; the -2.0 factor promotes the quotient to double
     const double denom = (fade == 0.5f) ? (double)1.3862943611198906f : -2.0 * (double)std::log(fade);

@@ -136,6 +136,9 @@ GS4D_API void gs4d_host_look_at(const float eye[3], const float orientation[3], 
 GS4D_API void gs4d_host_perspective(float fov_deg, int width, int height, float znear, float zfar, float proj[16]);             /* Camera.cpp:55-58 */
 GS4D_API void gs4d_host_quat_look_at(const float dir[3], const float up[3], float q_wxyz[4]);                                   /* Scenes.h:268     */
 GS4D_API void gs4d_host_splat3d_cov(const float q_wxyz[4], const float scale[3], float cov9[9]);                                /* Splat.h:334-344  */
+GS4D_API void gs4d_host_splat3d_mesh(const float pos3[3], const float q_wxyz[4], const float scale[3], const float color4[4], float verts72[72]); /* Splat.h:433-473, Geometry.h:37-50: the 4 x 72-byte vertices gs4d_draw_quads takes */
+GS4D_API void gs4d_host_splat2d_sigma_inv(const float v0[2], float l0, float l1, float sigma_inv4[4]);                             /* Splat.h:551-582  */
+GS4D_API void gs4d_host_gaussians2d_record(float angle, float s0, float s1, float px, float py, const float rgb[3], float rec12[12]); /* Scenes.h:1490-1496: one 48-byte GS4D_MODE_2D record */
 GS4D_API void gs4d_host_splat4d_cov(const float q_wxyz[4], const float scale[3], float lifetime, float fade, const float dir[3], float cov16[16]); /* Splat.h:132-159 */
 GS4D_API void gs4d_host_splat4d_cov2q(const float q0_wxyz[4], const float q1_wxyz[4], const float scale4[4], float cov16[16]);   /* Splat.h:91-130   */
 /* Batch builders: n splats -> n 96-byte SplatData records (Scenes.h:22-37 layout).

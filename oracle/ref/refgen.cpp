@@ -375,6 +375,57 @@ int main(int argc, char** argv) {
         for (auto& m : sd) recs.push_back({ glm::vec4{ oscale * m.pos, 0.0 }, m.color, m.cov });
         dump("synthetic_sd_records", "f32", recs.data(), recs.size() * 24, 24);
     }
+    // ---- (14) Splat3D::GetSplatMesh (Splat.h:433-447): four 72-byte vertices {corner, position, colour, Sigma3} per splat
+    {
+        std::vector<float> in, out;
+        for (int i = 0; i < 24; ++i) {
+            glm::vec4 pos{ 0.5f * float(i) - 3.0f, 0.25f * float(i % 5), -1.5f + 0.125f * float(i), 1.0f };
+            glm::quat q = glm::normalize(glm::quat(1.0f + 0.1f * float(i), 0.3f * float(i % 4) - 0.2f, 0.7f - 0.05f * float(i), 0.11f * float(i % 7)));
+            glm::vec3 sc{ 0.5f + 0.25f * float(i % 3), 1.0f + 0.125f * float(i % 5), 0.25f + 0.0625f * float(i) };
+            glm::vec4 col{ 0.04f * float(i), 1.0f - 0.03f * float(i), 0.5f, 0.25f + 0.03f * float(i) };
+            std::vector<Geometry::Splat3DVertex> v = Splat3D::GetSplatMesh(pos, q, sc, col);
+            static_assert(sizeof(Geometry::Splat3DVertex) == 72, "Splat3DVertex must be 72 bytes");
+            const float row[15] = { pos.x, pos.y, pos.z, pos.w, q.w, q.x, q.y, q.z, sc.x, sc.y, sc.z, col.x, col.y, col.z, col.w };
+            in.insert(in.end(), row, row + 15);
+            const float* f = reinterpret_cast<const float*>(v.data());
+            out.insert(out.end(), f, f + 72);
+        }
+        dump("splat3d_mesh_in", "f32", in.data(), in.size(), 15);
+        dump("splat3d_mesh_verts", "f32", out.data(), out.size(), 72);
+    }
+    // ---- (15) Splat2D (Splat.h:551-582: CalcAndSetSigma) and the Gaussians2D record expression (Scenes.h:1490-1496) for given
+    // angle / scales / position / colour (the scene draws them from RANDOM)
+    {
+        std::vector<float> in, out, in2, out2;
+        for (int i = 0; i < 32; ++i) {
+            glm::vec2 v0{ cosf(0.37f * float(i)) * (1.0f + 0.1f * float(i % 3)), sinf(0.37f * float(i)) * 1.5f };
+            const float l0 = 0.25f + 0.3f * float(i % 6), l1 = 4.0f - 0.11f * float(i);
+            Splat2D s2{ glm::vec3{ 0.0f, 0.0f, 0.0f }, v0, l0, l1, glm::vec4{ 1.0f } };
+            // mSigma is private and only leaves the class through Shader::SetUniformMat2f: the four statements of CalcAndSetSigma
+            // (Splat.h:576-582) are restated on the members the class does expose (glm does the arithmetic)
+            glm::mat2 S_(s2.GetLambda0(), 0.0f, 0.0f, s2.GetLambda1());
+            glm::mat2 R_(s2.GetVector(), glm::normalize(glm::vec2(v0.y, -v0.x)));
+            glm::mat2 sg = glm::inverse(R_ * S_ * glm::transpose(S_) * glm::transpose(R_));
+            const float row[4] = { v0.x, v0.y, l0, l1 };
+            in.insert(in.end(), row, row + 4);
+            out.insert(out.end(), &sg[0][0], &sg[0][0] + 4);
+            const float a = glm::radians(360.0f * (float(i) / 32.0f + 0.013f));
+            const float s0 = 1.0f + (5.0f * (0.03f * float(i))), s1 = 1.0f + (5.0f * (1.0f - 0.029f * float(i)));
+            const float px = 10.0f * (-0.5f + 0.031f * float(i)), py = 10.0f * (-0.5f + (1.0f - 0.03f * float(i)));
+            glm::mat2 R{ cosf(a), -sinf(a), sinf(a), cos(a) };
+            glm::mat2 S{ s0, 0.0f, 0.0f, s1 };
+            struct Splat2DData { glm::vec4 position; glm::vec4 color; glm::mat2 geoinfo; } d{ { px, py, 0, 0 }, { 0.1f * float(i % 10), 0.5f, 1.0f - 0.02f * float(i), 1.0 }, R * S * S * glm::transpose(R) };
+            static_assert(sizeof(d) == 48, "Splat2DData must be 48 bytes");
+            const float row2[8] = { a, s0, s1, px, py, d.color.x, d.color.y, d.color.z };
+            in2.insert(in2.end(), row2, row2 + 8);
+            const float* f = reinterpret_cast<const float*>(&d);
+            out2.insert(out2.end(), f, f + 12);
+        }
+        dump("splat2d_sigma_in", "f32", in.data(), in.size(), 4);
+        dump("splat2d_sigma_inv", "f32", out.data(), out.size(), 4);
+        dump("gaussians2d_in", "f32", in2.data(), in2.size(), 8);
+        dump("gaussians2d_records", "f32", out2.data(), out2.size(), 12);
+    }
     fprintf(g_manifest, "\n}\n"); fclose(g_manifest);
     printf("refgen: fixtures written to %s\n", g_out.c_str());
     return 0;

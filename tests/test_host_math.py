@@ -111,3 +111,15 @@ def test_sd_loader(gs4d, oracle, tmp_path):
     p = tmp_path / "cut.sd"
     p.write_text(" ".join(txt[:23 * 3 + 7]))
     assert np.array_equal(gs4d.parse_sd(str(p), object_scale=2.5), rec[:3])
+
+
+def test_splat3d_mesh_and_2d_records(gs4d, oracle):
+    """Splat3D::GetSplatMesh (Splat.h:433-447), Splat2D::CalcAndSetSigma (:576-582) and the Gaussians2D record expression
+    (Scenes.h:1490-1496) against the reference's own classes / glm arithmetic (oracle/ref/refgen.cpp items 14, 15)."""
+    for r, g in zip(oracle.golden("splat3d_mesh_in"), oracle.golden("splat3d_mesh_verts")):
+        v = gs4d.splat3d_mesh(r[0:3], r[4:8], r[8:11], r[11:15])
+        assert np.array_equal(bits(v.reshape(-1)), bits(g))
+    for r, g in zip(oracle.golden("splat2d_sigma_in"), oracle.golden("splat2d_sigma_inv")):
+        assert np.array_equal(bits(gs4d.splat2d_sigma_inv(r[0:2], float(r[2]), float(r[3]))), bits(g))
+    for r, g in zip(oracle.golden("gaussians2d_in"), oracle.golden("gaussians2d_records")):
+        assert np.array_equal(bits(gs4d.gaussians2d_record(float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4]), r[5:8])), bits(g))
