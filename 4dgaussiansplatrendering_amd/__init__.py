@@ -82,6 +82,7 @@ def _load():
         "gs4d_host_scene_square": (None, [sz, vp, i32, f32, f32, vp, f32, f32, f32, sz, vp]),
         "gs4d_host_parse_vdata": (C.c_long, [C.c_char_p, vp, sz]),
         "gs4d_host_parse_sd": (C.c_long, [C.c_char_p, f32, vp, sz]),
+        "gs4d_host_write_png": (i32, [C.c_char_p, vp, i32, i32]),
         "gs4d_version": (C.c_char_p, []),
     }
     for name, (res, args) in sig.items():
@@ -247,6 +248,15 @@ def parse_sd(path, object_scale=1.0, cap_records=1 << 22):
     if n < 0:
         raise FileNotFoundError(path)
     return buf[:min(n, cap_records)].copy()
+
+
+def write_png(path, rgba8):
+    """(H, W, 4) uint8 frame, bottom row first (the framebuffer's orientation) -> PNG file."""
+    a = np.ascontiguousarray(rgba8, np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4:
+        raise ValueError("write_png: expected an (H, W, 4) uint8 array")
+    if _lib.gs4d_host_write_png(os.fsencode(path), _ptr(a), a.shape[1], a.shape[0]) != 0:
+        raise OSError(f"cannot write {path}")
 
 
 # ---- device context -----------------------------------------------------------------------------

@@ -11,7 +11,9 @@
 //   SplatData record layout                          4DSplatRendering/Scenes.h:22-37
 // GLM 0.9.9.9 evaluation order is reproduced (float32, no contraction: build with -ffp-contract=off).
 #include "../../include/gs4d.h"
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -459,6 +461,51 @@ long gs4d_host_parse_sd(const char* path, float object_scale, float* records24, 
         std::memcpy(rec + 8, w + 7, 64);
     }
     return (long)n;
+}
+
+// Presentation: the packed RGBA8 frame (gs4d_read_pixels_rgba8_device, bottom row first like the GL window
+// framebuffer the reference presents, Application.cpp:89, 186) as a PNG file, top row first.  Self-contained: stored (uncompressed)
+// deflate blocks, CRC-32 and Adler-32 computed here.  Returns 0, or -1 if the file cannot be written.
+int gs4d_host_write_png(const char* path, const uint8_t* rgba8, int width, int height) {
+    if (!path || !rgba8 || width <= 0 || height <= 0) return -1;
+    static uint32_t table[256]; static bool have = false;
+    if (!have) { for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; } have = true; }
+    auto crc = [&](uint32_t c, const uint8_t* p, size_t n) { for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 255u] ^ (c >> 8); return c; };
+    auto be32 = [](uint8_t* o, uint32_t v) { o[0] = (uint8_t)(v >> 24); o[1] = (uint8_t)(v >> 16); o[2] = (uint8_t)(v >> 8); o[3] = (uint8_t)v; };
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    bool ok = true;
+    auto chunk = [&](const char type[4], const std::vector<uint8_t>& data) {
+        uint8_t hdr[8]; be32(hdr, (uint32_t)data.size()); std::memcpy(hdr + 4, type, 4);
+        uint32_t c = crc(0xFFFFFFFFu, hdr + 4, 4); c = crc(c, data.data(), data.size()) ^ 0xFFFFFFFFu;
+        uint8_t tail[4]; be32(tail, c);
+        ok = ok && fwrite(hdr, 1, 8, f) == 8 && (data.empty() || fwrite(data.data(), 1, data.size(), f) == data.size()) && fwrite(tail, 1, 4, f) == 4;
+    };
+    static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    ok = fwrite(sig, 1, 8, f) == 8;
+    std::vector<uint8_t> ihdr(13); be32(ihdr.data(), (uint32_t)width); be32(ihdr.data() + 4, (uint32_t)height);
+    ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;            // 8 bits, RGBA, deflate, no filter method, no interlace
+    chunk("IHDR", ihdr);
+    // raw scanlines: filter byte 0 + row, top row first (the framebuffer's row 0 is the bottom row)
+    const size_t stride = (size_t)width * 4, raw_n = (stride + 1) * (size_t)height;
+    std::vector<uint8_t> raw(raw_n);
+    for (int y = 0; y < height; ++y) { uint8_t* o = raw.data() + (stride + 1) * (size_t)y; o[0] = 0; std::memcpy(o + 1, rgba8 + stride * (size_t)(height - 1 - y), stride); }
+    std::vector<uint8_t> z; z.reserve(raw_n + raw_n / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    for (size_t off = 0; off < raw_n;) {
+        const size_t n = std::min<size_t>(65535, raw_n - off);
+        z.push_back(off + n == raw_n ? 1 : 0);
+        z.push_back((uint8_t)(n & 255)); z.push_back((uint8_t)(n >> 8)); z.push_back((uint8_t)(~n & 255)); z.push_back((uint8_t)((~n >> 8) & 255));
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        off += n;
+    }
+    uint32_t a = 1, b = 0;
+    for (size_t i = 0; i < raw_n; ++i) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+    uint8_t ad[4]; be32(ad, (b << 16) | a); z.insert(z.end(), ad, ad + 4);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    ok = (fclose(f) == 0) && ok;
+    return ok ? 0 : -1;
 }
 
 } // extern "C"

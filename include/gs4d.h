@@ -165,6 +165,9 @@ GS4D_API long gs4d_host_parse_vdata(const char* path, float* verts6, size_t cap_
 /* .sd splat files (23 numbers per splat) -> 96-byte records as ObjectDisplay::init builds them; returns the splat count or -1 */
 GS4D_API long gs4d_host_parse_sd(const char* path, float object_scale, float* records24, size_t cap_records);           /* VDataParser.h:60-123, Scenes.h:2483-2491 */
 
+/* Presentation: an RGBA8 frame as produced by gs4d_read_pixels_rgba8_device (bottom row first) -> PNG file */
+GS4D_API int gs4d_host_write_png(const char* path, const uint8_t* rgba8, int width, int height);
+
 GS4D_API const char* gs4d_version(void);
 
 #ifdef __cplusplus

@@ -123,3 +123,31 @@ def test_splat3d_mesh_and_2d_records(gs4d, oracle):
         assert np.array_equal(bits(gs4d.splat2d_sigma_inv(r[0:2], float(r[2]), float(r[3]))), bits(g))
     for r, g in zip(oracle.golden("gaussians2d_in"), oracle.golden("gaussians2d_records")):
         assert np.array_equal(bits(gs4d.gaussians2d_record(float(r[0]), float(r[1]), float(r[2]), float(r[3]), float(r[4]), r[5:8])), bits(g))
+
+
+def test_png_writer(gs4d, tmp_path):
+    """Presentation: the PNG the library writes decodes (zlib + CRC checks, done here by hand) to the frame it was
+    given, top row first."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(3)
+    h, w = 37, 53
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    p = tmp_path / "f.png"
+    gs4d.write_png(str(p), img)
+    raw = p.read_bytes()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        data = raw[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + data)
+        chunks.append((typ, data))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 6, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + 4 * w)
+    assert np.all(rows[:, 0] == 0)
+    assert np.array_equal(rows[:, 1:].reshape(h, w, 4), img[::-1])
+    with pytest.raises(OSError):
+        gs4d.write_png(str(tmp_path / "no_such_dir" / "f.png"), img)
