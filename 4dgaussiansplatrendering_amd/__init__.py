@@ -56,6 +56,7 @@ def _load():
         "gs4d_read_pixels": (i32, [vp, vp, sz]),
         "gs4d_read_pixels_device": (i32, [vp, vp, sz]),
         "gs4d_read_pixels_rgba8_device": (i32, [vp, vp, sz]),
+        "gs4d_read_frame_rgba8_device": (i32, [vp, i32, vp, sz]),
         "gs4d_set_stream": (i32, [vp, vp]),
         "gs4d_finish": (i32, [vp]),
         "gs4d_set_profiling": (i32, [vp, i32]),
@@ -364,6 +365,10 @@ class Context:
 
     def read_pixels_rgba8_device(self, dptr, nbytes):
         self._chk(_lib.gs4d_read_pixels_rgba8_device(self._h, C.c_void_p(dptr), nbytes))
+
+    def read_frame_rgba8_device(self, frames_back, dptr, nbytes):
+        """Pack the current (0) or the previous (1) image of the swap chain to RGBA8 at device pointer `dptr`, asynchronously."""
+        self._chk(_lib.gs4d_read_frame_rgba8_device(self._h, frames_back, C.c_void_p(dptr), nbytes))
 
     def set_stream(self, hip_stream):
         self._chk(_lib.gs4d_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))

@@ -75,6 +75,8 @@ struct Lane {
     uint32_t* host_total = nullptr;     // pinned + mapped: [0..3] the binning total of the last draw, [4] the error word kernels raise
     uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
     gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
+    bool pending = false;              // the lane's last draw has not had its tile-list capacity validated yet
+    DrawArgs pending_args;
 };
 
 thread_local std::string g_create_error;
@@ -99,8 +101,7 @@ struct gs4d_ctx {
     float clear[4] = { 0.0f, 0.0f, 0.0f, 0.0f };     // GL's initial clear colour; the app sets its own (Application.cpp:125)
     bool atomic_rank = false;          // result of the LDS-atomic ordering self-test
     uint64_t ops = 0, synced = 0;      // device-side uses so far / at the last sync of every lane
-    bool pending = false;              // the last draw's tile-list capacity has not been validated yet
-    DrawArgs pending_args;
+    int prev_fb = -1;                  // the image the last gs4d_clear moved away from (still intact until its lane comes round again)
     uint64_t stat_entries = 0, stat_reruns = 0, stat_depth_passes = 0, stat_tile_passes = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
     static constexpr int PROF_FRAMES = 128;
@@ -335,11 +336,11 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
 // A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
 // Called by every entry point that could observe the draw's result.  On overflow the raster stages are re-run with exact capacity
 // (the projected records and the copy of the sort index are still valid).
-int resolve_pending(gs4d_ctx* c) {
-    while (c->pending) {
-        Lane& L = c->lanes[c->pending_args.lane];
+int resolve_lane(gs4d_ctx* c, int li) {
+    Lane& L = c->lanes[li];
+    while (L.pending) {
         HIPCHK(c, hipEventSynchronize(L.ev_emit));     // the entry count is final once the binning kernel has run
-        c->pending = false;
+        L.pending = false;
         if (L.host_total[4]) return fail(c, GS4D_E_DEVICE, DEVICE_CHECK_MSG);
         const uint64_t total = (uint64_t)L.host_total[2] | ((uint64_t)L.host_total[3] << 32);
         if (!L.host_total[1]) { c->stat_entries = total; break; }
@@ -348,10 +349,23 @@ int resolve_pending(gs4d_ctx* c) {
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;
         c->stat_entries = total;
-        rc = run_draw(c, c->pending_args, false);
+        rc = run_draw(c, L.pending_args, false);
         if (rc) return rc;
-        c->pending = true;
+        L.pending = true;
     }
+    return GS4D_OK;
+}
+
+// every lane (calls that observe or tear down everything)
+int resolve_pending(gs4d_ctx* c) {
+    for (int i = 0; i < c->nlanes; ++i) { int rc = resolve_lane(c, i); if (rc) return rc; }
+    return GS4D_OK;
+}
+
+// the draws that rendered into image `fb` (calls that observe that image)
+int resolve_image(gs4d_ctx* c, int fb) {
+    for (int i = 0; i < c->nlanes; ++i)
+        if (c->lanes[i].pending && c->lanes[i].pending_args.fb == fb) { int rc = resolve_lane(c, i); if (rc) return rc; }
     return GS4D_OK;
 }
 
@@ -568,13 +582,16 @@ int gs4d_set_blend(gs4d_ctx* c, int src, int dst) {
 int gs4d_clear(gs4d_ctx* c) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
-    // Whatever a still-unvalidated draw left in the framebuffer is discarded by the clear.
-    c->pending = false;
     int rc = next_frame_if_drawn(c); if (rc) return rc;
     // the new frame renders into the current lane's own framebuffer (a swap chain with one image per lane); the clear itself is
-    // lazy: the compositing kernel starts from the clear colour instead of reading the pixels
+    // lazy: the compositing kernel starts from the clear colour instead of reading the pixels.  The image left behind stays intact
+    // (and readable: gs4d_read_frame_*) until its lane comes round again.
+    if (c->cur != c->cur_fb) c->prev_fb = c->cur_fb;
+    else if (c->nlanes == 1) c->prev_fb = -1;
     c->cur_fb = c->cur;
     c->fbs[c->cur_fb].is_clear = true;
+    // whatever a still-unvalidated draw left in the image that is being cleared is discarded with it
+    for (int i = 0; i < c->nlanes; ++i) if (c->lanes[i].pending && c->lanes[i].pending_args.fb == c->cur_fb) c->lanes[i].pending = false;
     return GS4D_OK;
 }
 
@@ -658,7 +675,10 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
 // ---- draw ----
 static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     (void)hipSetDevice(c->device);
-    int rc = resolve_pending(c); if (rc) return rc;
+    // the lane's scratch still belongs to its previous draw, and the image this draw blends onto must be complete: validate those
+    // (not the other lanes' draws: their frames are still in flight and nothing here depends on them)
+    int rc = resolve_lane(c, c->cur); if (rc) return rc;
+    rc = resolve_image(c, c->cur_fb); if (rc) return rc;
     rc = after_user_stream(c); if (rc) return rc;
     Lane& L = lane(c);
     a.lane = c->cur; a.fb = c->cur_fb;
@@ -667,7 +687,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     L.proj_n = 0;
     rc = run_draw(c, a, true);
     if (rc) { L.proj_n = before; return rc; }
-    if (L.proj_n) { c->pending = true; c->pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; }   // proj_n != 0 <=> raster work was enqueued
+    if (L.proj_n) { L.pending = true; L.pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; }   // proj_n != 0 <=> raster work was enqueued
     else L.proj_n = before;
     if (c->profiling) { if (c->prof_frame < gs4d_ctx::PROF_FRAMES && c->prof_tick % (uint64_t)c->prof_every == 0) c->prof_frame++; c->prof_tick++; }
     return GS4D_OK;
@@ -703,7 +723,7 @@ int gs4d_read_pixels(gs4d_ctx* c, float* rgba, size_t bytes) {
     if (!c || !rgba) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels: bytes != width*height*16");
-    int rc = resolve_pending(c); if (rc) return rc;
+    int rc = resolve_image(c, c->cur_fb); if (rc) return rc;
     rc = materialise_fb(c); if (rc) return rc;
     Framebuffer& F = c->fbs[c->cur_fb];
     rc = fb_access(c, F); if (rc) return rc;
@@ -713,15 +733,26 @@ int gs4d_read_pixels(gs4d_ctx* c, float* rgba, size_t bytes) {
     return GS4D_OK;
 }
 
-static int read_device_common(gs4d_ctx* c, void* dptr, bool rgba8) {
-    int rc = resolve_pending(c); if (rc) return rc;
-    rc = after_user_stream(c); if (rc) return rc;          // the destination may still be in use by the caller's earlier work
-    rc = materialise_fb(c); if (rc) return rc;
-    Framebuffer& F = c->fbs[c->cur_fb];
-    rc = fb_access(c, F); if (rc) return rc;
-    Lane& L = lane(c);
+// frames_back 0: the image the last clear / draw used.  1: the image the last gs4d_clear moved away from (the previous frame of the
+// swap chain) — it is packed on the lane that rendered it, behind its compositing kernel, so an application that reads frame f-1
+// after queueing frame f never waits for frame f.
+static int read_device_common(gs4d_ctx* c, int frames_back, void* dptr, bool rgba8) {
+    if (frames_back != 0 && frames_back != 1) return fail(c, GS4D_E_INVALID, "read_frame: frames_back must be 0 or 1");
+    const int fi = frames_back == 0 ? c->cur_fb : c->prev_fb;
+    if (fi < 0) return fail(c, GS4D_E_INVALID, "read_frame: no previous image is retained (one frame lane, or no gs4d_clear yet)");
+    int rc = resolve_image(c, fi); if (rc) return rc;
+    Framebuffer& F = c->fbs[fi];
+    const int li = (fi == c->cur_fb || F.last_lane < 0) ? c->cur : F.last_lane;
+    Lane& L = c->lanes[li];
+    if (c->user) {                                          // the destination may still be in use by the caller's earlier work
+        HIPCHK(c, hipEventRecord(c->ev_user, c->user));
+        HIPCHK(c, hipStreamWaitEvent(L.s, c->ev_user, 0));
+    }
+    if (li == c->cur) { rc = fb_access(c, F); if (rc) return rc; }
+    if (F.is_clear) { HIPCHK(c, launch_fill(L.s, F.mem, (size_t)c->W * c->H, c->clear)); F.is_clear = false; }
     if (rgba8) HIPCHK(c, launch_pack_rgba8(L.s, F.mem, (size_t)c->W * c->H, (uint32_t*)dptr));
     else HIPCHK(c, hipMemcpyAsync(dptr, F.mem, (size_t)c->W * c->H * 16, hipMemcpyDeviceToDevice, L.s));
+    if (li != c->cur) HIPCHK(c, hipEventRecord(L.ev_tail, L.s));      // the lane's tail event keeps covering everything queued on it
     if (c->user) {                                          // work the caller queues on its stream after this call sees the pixels
         HIPCHK(c, hipEventRecord(c->ev_readback, L.s));
         HIPCHK(c, hipStreamWaitEvent(c->user, c->ev_readback, 0));
@@ -733,14 +764,21 @@ int gs4d_read_pixels_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (!c || !dptr) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels_device: bytes != width*height*16");
-    return read_device_common(c, dptr, false);
+    return read_device_common(c, 0, dptr, false);
 }
 
 int gs4d_read_pixels_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (!c || !dptr) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_pixels_rgba8_device: bytes != width*height*4");
-    return read_device_common(c, dptr, true);
+    return read_device_common(c, 0, dptr, true);
+}
+
+int gs4d_read_frame_rgba8_device(gs4d_ctx* c, int frames_back, void* dptr, size_t bytes) {
+    if (!c || !dptr) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_frame_rgba8_device: bytes != width*height*4");
+    return read_device_common(c, frames_back, dptr, true);
 }
 
 int gs4d_set_stream(gs4d_ctx* c, void* hip_stream) {

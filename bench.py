@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--keybufs", type=int, default=2, help="per-frame key / sort-index buffer pairs the application cycles through")
+    ap.add_argument("--readback", action="store_true", help="N=1 only: also pack every frame to RGBA8 on the device, as the multi-GPU path does before its gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
     args = ap.parse_args()
@@ -100,8 +101,9 @@ def main():
 
     frame8 = gathered = None
     gdev = "cuda" if backend == "nccl" else "cpu"
-    if multi:
+    if multi or args.readback:
         frame8 = torch.empty(H * W, dtype=torch.int32, device="cuda")
+    if multi:
         gathered = [torch.empty(H * W, dtype=torch.int32, device=gdev) for _ in range(world)] if rank == 0 else None
 
     sharding = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
@@ -117,11 +119,33 @@ def main():
         ctx.sort_pairs(keys, idx, n)
         ctx.bind(1, idx)
         ctx.draw_instanced(n)
+        # Presentation is software-pipelined, as a swap chain is: frame k is queued first, then frame k-1 (the previous image) is
+        # packed to RGBA8 and gathered — its lane finished long ago, so the host never waits for the frame it has just queued.
+        if multi or args.readback:
+            if not pipelined:
+                present(0)
+                return
+            if state["unsent"]:
+                present(1)
+        state["unsent"] = True
+
+    state = {"unsent": False}
+    pipelined = ctx.stats()["lanes"] >= 2          # with one frame lane there is no previous image to read
+
+    def present(frames_back):
+        ctx.read_frame_rgba8_device(frames_back, frame8.data_ptr(), frame8.numel() * 4)
         if multi:
-            ctx.read_pixels_rgba8_device(frame8.data_ptr(), frame8.numel() * 4)
             sharding.gather_frames(dist, frame8 if backend == "nccl" else frame8.cpu(), gathered, dst=0)
+        state["unsent"] = False
+
+    def flush():
+        # the last frame of a region is presented inside that region: K steps render K frames and gather K frames
+        if (multi or args.readback) and state["unsent"]:
+            present(0)
+        state["unsent"] = False
 
     def fence():
+        flush()
         ctx.finish()
         torch.cuda.synchronize()
         if multi:

@@ -110,6 +110,11 @@ GS4D_API int gs4d_read_pixels_device(gs4d_ctx* ctx, void* dptr, size_t bytes);  
 /* Presentation format of the reference's window framebuffer (RGBA8 unorm, Application.cpp:89): clamp to [0,1], round to nearest.
  * Device-to-device, asynchronous like gs4d_read_pixels_device, width*height*4 bytes. */
 GS4D_API int gs4d_read_pixels_rgba8_device(gs4d_ctx* ctx, void* dptr, size_t bytes);
+/* The same for an image of the swap chain: frames_back 0 = the current image, 1 = the image the last gs4d_clear moved away from (the
+ * previous frame), which stays intact until its lane comes round again.  An application that reads frame f-1 after queueing frame f
+ * (clear, keygen, sort, draw) never waits for frame f: its host thread stays ahead of the device.  GS4D_E_INVALID when there is no such
+ * image (frames_back > 1, one frame lane, or no gs4d_clear yet). */
+GS4D_API int gs4d_read_frame_rgba8_device(gs4d_ctx* ctx, int frames_back, void* dptr, size_t bytes);
 /* Name the caller's HIP stream (hipStream_t passed as void*; NULL: none).  The library keeps running on its own streams, but from now
  * on (a) whatever the caller queued on that stream before an enqueueing call (keygen, sort, draw, device read-back) happens before the
  * work of that call — e.g. a kernel of the caller's that fills a buffer obtained with gs4d_buffer_device_ptr — and (b) whatever the

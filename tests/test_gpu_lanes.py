@@ -149,3 +149,52 @@ def test_subdata_while_frames_in_flight(lanes_ctx, gs4d, oracle):
             ctx.draw_instanced(n)
         assert np.max(np.abs(ctx.read_pixels() - _expected(oracle, r, 5.0, view, proj))) <= TOL
     ctx.finish()
+
+
+def test_previous_image_of_the_swap_chain(lanes_ctx, gs4d, oracle):
+    """gs4d_read_frame_rgba8_device(1): frame f-1 is packed after frame f has been queued (software-pipelined presentation); it must
+    be frame f-1's pixels, whatever is in flight.  RGBA8: round(clamp(x) * 255); one LSB of slack for pixels on a rounding boundary."""
+    ctx = lanes_ctx
+    rec = _records(gs4d, 20000)
+    n = rec.shape[0]
+    view, proj = _mats(gs4d)
+    data = ctx.buffer(rec)
+    kb = [(ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)) for _ in range(2)]
+    outs = [ctx.buffer(nbytes=W * H * 4) for _ in range(5)]
+    ctx.bind(2, data)
+    times = [0.0, 9.0, 18.0, 27.0, 36.0]
+    lanes = ctx.stats()["lanes"]
+
+    def queue(f):
+        keys, idx = kb[f % 2]
+        ctx.clear()
+        ctx.set_uniforms(time=times[f], min_opacity=0.0, view=view, proj=proj)
+        ctx.keygen(data, times[f], CAM[0], keys, idx, n)
+        ctx.sort_pairs(keys, idx, n)
+        ctx.bind(1, idx)
+        ctx.draw_instanced(n)
+
+    if lanes == 1:
+        queue(0)
+        with pytest.raises(gs4d.Gs4dError):
+            ctx.read_frame_rgba8_device(1, ctx.device_ptr(outs[0])[0], W * H * 4)
+        ctx.read_frame_rgba8_device(0, ctx.device_ptr(outs[0])[0], W * H * 4)
+        shown = [0]
+    else:
+        with pytest.raises(gs4d.Gs4dError):
+            ctx.read_frame_rgba8_device(1, ctx.device_ptr(outs[0])[0], W * H * 4)      # no clear yet: no previous image
+        for f in range(len(times)):
+            queue(f)
+            if f > 0:
+                ctx.read_frame_rgba8_device(1, ctx.device_ptr(outs[f - 1])[0], W * H * 4)
+        ctx.read_frame_rgba8_device(0, ctx.device_ptr(outs[-1])[0], W * H * 4)
+        with pytest.raises(gs4d.Gs4dError):
+            ctx.read_frame_rgba8_device(2, ctx.device_ptr(outs[0])[0], W * H * 4)
+        shown = list(range(len(times)))
+    ctx.finish()
+    for f in shown:
+        got = ctx.read(outs[f], np.uint8, W * H * 4).reshape(H, W, 4).astype(np.int32)
+        e = _expected(oracle, rec, times[f], view, proj)
+        want = np.rint(np.clip(e, 0.0, 1.0) * 255.0).astype(np.int32)
+        d = np.abs(got - want)
+        assert d.max() <= 1 and np.count_nonzero(d) <= 64, f"frame {f}: max {d.max()}, {np.count_nonzero(d)} differing bytes"
