@@ -208,6 +208,7 @@ hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size
     size_t nb = (ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS);
     if (nb < 1) nb = 1;
     if (!b.total) {
+        if (const char* e0 = getenv("GS4D_TEST_EPOCH0")) b.epoch = ((uint32_t)strtoul(e0, nullptr, 0) << 4) | 0xFu;     // test hook: 22-bit wrap within a short test
         if ((e = hipMalloc(&b.total, 64)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(b.total, 0, 64, st)) != hipSuccess) return e;
         b.ticket_base = 0;

@@ -492,6 +492,10 @@ hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n) {
         }
         s.hist = nh; s.hist_cap = words;
     }
+    if (!s.totals) {
+        // test hook: start the epoch counter close to its 18-bit wrap so that a short test crosses it
+        if (const char* e0 = getenv("GS4D_TEST_EPOCH0")) s.epoch = (uint32_t)strtoul(e0, nullptr, 0);
+    }
     if (!s.totals) { if ((e = hipMalloc(&s.totals, 256 * 4)) != hipSuccess) return e; if ((e = hipMemsetAsync(s.totals, 0, 1024, st)) != hipSuccess) return e; }
     return hipSuccess;
 }

@@ -198,3 +198,54 @@ def test_previous_image_of_the_swap_chain(lanes_ctx, gs4d, oracle):
         want = np.rint(np.clip(e, 0.0, 1.0) * 255.0).astype(np.int32)
         d = np.abs(got - want)
         assert d.max() <= 1 and np.count_nonzero(d) <= 64, f"frame {f}: max {d.max()}, {np.count_nonzero(d)} differing bytes"
+
+
+def test_look_back_epochs_wrap(gs4d, oracle):
+    """The look-back words of the chained scans are tagged with a launch counter (18 bits in the sort, 22 in the binning kernel) instead
+    of being zeroed; when the counter wraps, the words are cleared once.  GS4D_TEST_EPOCH0 starts the counters a few launches before
+    the wrap so that this test crosses it: sorts and frames on both sides of the wrap must be right."""
+    old = os.environ.get("GS4D_TEST_EPOCH0")
+    os.environ["GS4D_TEST_EPOCH0"] = str(0x3FFF0)           # 16 launches before 2^18; binning: (0x3FFF0 << 4 | 15) = 2^22 - 241
+    try:
+        ctx = gs4d.Context(W, H)
+        ctx.set_clear_color(gs4d.CLEAR_COLOR)
+        ctx.set_mode(gs4d.MODE_4D_SORTED)
+        rng = np.random.default_rng(11)
+        n = 300000
+        for _ in range(12):                                  # 12 x (1 histogram + 4 passes): crosses the sort's wrap
+            keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+            kb, vb = ctx.buffer(keys), ctx.buffer(np.arange(n, dtype=np.uint32))
+            ctx.sort_pairs(kb, vb, n)
+            ek, ev = oracle.sort_pairs(keys, np.arange(n, dtype=np.uint32), "lsd")
+            assert np.array_equal(ctx.read(kb, np.uint32, n), ek) and np.array_equal(ctx.read(vb, np.uint32, n), ev)
+            ctx.delete(kb)
+            ctx.delete(vb)
+        rec = _records(gs4d, 20000)
+        m = rec.shape[0]
+        view, proj = _mats(gs4d)
+        data, keys, idx = ctx.buffer(rec), ctx.buffer(nbytes=4 * m), ctx.buffer(nbytes=4 * m)
+        ctx.bind(2, data)
+        ctx.set_uniforms(time=4.0, min_opacity=0.0, view=view, proj=proj)
+        e = _expected(oracle, rec, 4.0, view, proj)
+        for f in range(300):                                 # 150 binning launches per lane so far: the binning wrap is 241 launches away...
+            ctx.clear()
+            ctx.keygen(data, 4.0, CAM[0], keys, idx, m)
+            ctx.sort_pairs(keys, idx, m)
+            ctx.bind(1, idx)
+            ctx.draw_instanced(m)
+            if f % 60 == 59:
+                assert np.max(np.abs(ctx.read_pixels() - e)) <= TOL, f"frame {f}"
+        for f in range(300, 600):                            # ... and is crossed on both lanes in here
+            ctx.clear()
+            ctx.keygen(data, 4.0, CAM[0], keys, idx, m)
+            ctx.sort_pairs(keys, idx, m)
+            ctx.bind(1, idx)
+            ctx.draw_instanced(m)
+            if f % 60 == 59:
+                assert np.max(np.abs(ctx.read_pixels() - e)) <= TOL, f"frame {f}"
+        ctx.close()
+    finally:
+        if old is None:
+            del os.environ["GS4D_TEST_EPOCH0"]
+        else:
+            os.environ["GS4D_TEST_EPOCH0"] = old
