@@ -57,6 +57,9 @@ def _load():
         "gs4d_read_pixels_device": (i32, [vp, vp, sz]),
         "gs4d_read_pixels_rgba8_device": (i32, [vp, vp, sz]),
         "gs4d_read_frame_rgba8_device": (i32, [vp, i32, vp, sz]),
+        "gs4d_set_tile_shard": (i32, [vp, i32, i32]),
+        "gs4d_band_rows": (i32, [vp, vp]),
+        "gs4d_read_band_rgba8_device": (i32, [vp, vp, sz]),
         "gs4d_set_stream": (i32, [vp, vp]),
         "gs4d_finish": (i32, [vp]),
         "gs4d_set_profiling": (i32, [vp, i32]),
@@ -369,6 +372,18 @@ class Context:
     def read_frame_rgba8_device(self, frames_back, dptr, nbytes):
         """Pack the current (0) or the previous (1) image of the swap chain to RGBA8 at device pointer `dptr`, asynchronously."""
         self._chk(_lib.gs4d_read_frame_rgba8_device(self._h, frames_back, C.c_void_p(dptr), nbytes))
+
+    def set_tile_shard(self, rank, world):
+        """Single-frame sharding: this context bins and composites the tile rows ty % world == rank only."""
+        self._chk(_lib.gs4d_set_tile_shard(self._h, rank, world))
+
+    def band_rows(self):
+        n = C.c_int(0)
+        self._chk(_lib.gs4d_band_rows(self._h, C.byref(n)))
+        return n.value
+
+    def read_band_rgba8_device(self, dptr, nbytes):
+        self._chk(_lib.gs4d_read_band_rgba8_device(self._h, C.c_void_p(dptr), nbytes))
 
     def set_stream(self, hip_stream):
         self._chk(_lib.gs4d_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))

@@ -42,14 +42,14 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum /
     return base + inc - v;
 }
 
-struct Rect { uint32_t tx0, ty0, tx1, ty1, count; };
+struct Rect { uint32_t tx0, ty0, tx1, ty1, count, tstep; };     // tile rows ty0, ty0 + tstep, ... <= ty1 (tstep > 1: this context owns every tstep-th row)
 
 // writes the entries of one splat and counts their tile-id digits for the radix sort that follows (no separate histogram launch)
 __device__ __forceinline__ void emit_tiles(const Rect& r, uint32_t off, uint32_t rec, uint32_t tiles_x, uint32_t first, uint32_t stride,
                                            uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t (*h)[256], int passes) {
     const uint32_t wx = r.tx1 - r.tx0 + 1u;
     for (uint32_t j = first; j < r.count; j += stride) {
-        const uint32_t ty = r.ty0 + j / wx, tx = r.tx0 + j % wx;
+        const uint32_t ty = r.ty0 + (j / wx) * r.tstep, tx = r.tx0 + j % wx;
         const uint32_t id = ty * tiles_x + tx;
         pk[off + j] = id;
         pv[off + j] = rec;
@@ -73,7 +73,8 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
                                                           unsigned long long* status, unsigned long long* gstatus, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
                                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
-                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base, int dbg) {
+                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base, int dbg,
+                                                          uint32_t shard_rank, uint32_t shard_world /* tile row ty is ours iff ty % shard_world == shard_rank */) {
     __shared__ uint32_t wsum[BIN_WAVES];
     __shared__ unsigned long long s_prefix;
     __shared__ uint32_t s_blk;
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
 #pragma unroll
     for (int j = 0; j < BIN_ITEMS; ++j) {
         const uint32_t k = base + j * BIN_THREADS + tid;
-        r[j] = Rect{ 0, 0, 0, 0, 0 }; rec[j] = 0;
+        r[j] = Rect{ 0, 0, 0, 0, 0, 1 }; rec[j] = 0;
         if (k < ninst) {
             rec[j] = order ? order[k] : k;
             if (order_copy) order_copy[k] = rec[j];      // the draw keeps its own copy: the caller may refill the buffer for the next frame
@@ -99,7 +100,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
                 const uint32_t x0 = rr.x & 0xFFFFu, y0 = rr.x >> 16, x1 = rr.y & 0xFFFFu, y1 = rr.y >> 16;
                 if (x0 <= x1 && y0 <= y1) {
                     r[j].tx0 = x0 / TILE; r[j].ty0 = y0 / TILE; r[j].tx1 = x1 / TILE; r[j].ty1 = y1 / TILE;
-                    r[j].count = (r[j].tx1 - r[j].tx0 + 1u) * (r[j].ty1 - r[j].ty0 + 1u);
+                    uint32_t rows = r[j].ty1 - r[j].ty0 + 1u;
+                    if (shard_world > 1u) {            // only the tile rows this context owns (single-frame sharding over several GPUs)
+                        const uint32_t first = r[j].ty0 + (shard_rank + shard_world - r[j].ty0 % shard_world) % shard_world;
+                        rows = first > r[j].ty1 ? 0u : (r[j].ty1 - first) / shard_world + 1u;
+                        r[j].ty0 = first; r[j].tstep = shard_world;
+                    }
+                    r[j].count = (r[j].tx1 - r[j].tx0 + 1u) * rows;
                 }
             }
         }
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
             m &= m - 1;
             Rect rr;
             rr.tx0 = __shfl(r[j].tx0, src, 64); rr.ty0 = __shfl(r[j].ty0, src, 64); rr.tx1 = __shfl(r[j].tx1, src, 64); rr.ty1 = __shfl(r[j].ty1, src, 64);
-            rr.count = __shfl(r[j].count, src, 64);
+            rr.count = __shfl(r[j].count, src, 64); rr.tstep = __shfl(r[j].tstep, src, 64);
             const uint32_t o2 = __shfl(o, src, 64), rec2 = __shfl(rec[j], src, 64);
             emit_tiles(rr, o2, rec2, tiles_x, lane, 64u, pk, pv, h, passes);
         }
@@ -234,7 +241,7 @@ void bin_scratch_free(BinScratch& b) {
 }
 
 hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
-                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host) {
+                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host, int shard_rank, int shard_world) {
     (void)tiles_y;
     static const int dbg = getenv("GS4D_EMIT_DBG") ? atoi(getenv("GS4D_EMIT_DBG")) : 0;      // tuning aid (ablation): 1 no rect gather, 2 no histogram, 4 no writes
     if (++b.epoch >= (1u << 22)) {            // epoch wrap: forget every old word
@@ -243,7 +250,7 @@ hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, con
         b.epoch = 1;
     }
     const uint32_t nb = (uint32_t)((ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.status + b.block_cap, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch, b.total + 8, b.ticket_base, dbg);
+    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.status + b.block_cap, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch, b.total + 8, b.ticket_base, dbg, (uint32_t)shard_rank, (uint32_t)shard_world);
     b.ticket_base += nb;
     return hipGetLastError();
 }

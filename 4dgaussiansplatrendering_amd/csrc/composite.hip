@@ -43,6 +43,25 @@ hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, size_t npix, uint
     return hipGetLastError();
 }
 
+// Band of a tile-row-sharded frame: output row b belongs to the context's (b / TILE)-th tile row, i.e. tile row rank + (b / TILE) * world.
+__global__ __launch_bounds__(256) void k_pack_rgba8_band(const float4* __restrict__ fb, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t band_rows, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= band_rows * W) return;
+    const uint32_t b = i / W, x = i % W;
+    const uint32_t y = (rank + (b / (uint32_t)TILE) * world) * (uint32_t)TILE + b % (uint32_t)TILE;
+    if (y >= H) return;                                    // cannot happen for a band_rows computed by band_pixel_rows(); kept as a guard
+    const float4 v = fb[(size_t)y * W + x];
+    auto q = [](float f) { return (uint32_t)__float2int_rn(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f); };
+    out[i] = q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
+}
+
+hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, int W, int H, int rank, int world, int band_rows, uint32_t* out) {
+    if (band_rows <= 0) return hipSuccess;
+    const size_t n = (size_t)band_rows * W;
+    k_pack_rgba8_band<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(fb, (uint32_t)W, (uint32_t)H, (uint32_t)rank, (uint32_t)world, (uint32_t)band_rows, out);
+    return hipGetLastError();
+}
+
 // One chunk of <= 64 list entries is processed in one of two ways (wave-uniform choice):
 //  * splat-parallel (small footprints, the 10^6..10^7-splat cube configs: a quad covers ~3 of the tile's 64 pixels):
 //      phase A, lane = entry: evaluates the coverage rule only for the pixels of its own bounding box inside the tile and ORs its

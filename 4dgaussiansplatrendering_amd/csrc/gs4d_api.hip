@@ -101,6 +101,7 @@ struct gs4d_ctx {
     float clear[4] = { 0.0f, 0.0f, 0.0f, 0.0f };     // GL's initial clear colour; the app sets its own (Application.cpp:125)
     bool atomic_rank = false;          // result of the LDS-atomic ordering self-test
     uint64_t ops = 0, synced = 0;      // device-side uses so far / at the last sync of every lane
+    int shard_rank = 0, shard_world = 1;   // single-frame sharding: this context bins and composites the tile rows ty % world == rank
     int prev_fb = -1;                  // the image the last gs4d_clear moved away from (still intact until its lane comes round again)
     uint64_t stat_entries = 0, stat_reruns = 0, stat_depth_passes = 0, stat_tile_passes = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
@@ -253,7 +254,7 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, 
         uint32_t* ph = sort_hist_slot(L.s, L.pair_sort, L.pair_cap, &he);      // the emit kernel also counts the tile-id digits
         if (!ph) return hipfail(c, he, "sort_hist_slot");
         HIPCHK(c, launch_binning(L.s, L.bin, L.rects, order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, L.pair_keys, L.pair_vals, L.pair_cap, L.host_total_dev + 4,
-                                 ph, tile_passes, L.host_total_dev));
+                                 ph, tile_passes, L.host_total_dev, c->shard_rank, c->shard_world));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));     // the last binning workgroup wrote the total straight into pinned host memory
     {
@@ -779,6 +780,44 @@ int gs4d_read_frame_rgba8_device(gs4d_ctx* c, int frames_back, void* dptr, size_
     (void)hipSetDevice(c->device);
     if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_frame_rgba8_device: bytes != width*height*4");
     return read_device_common(c, frames_back, dptr, true);
+}
+
+static int band_pixel_rows(const gs4d_ctx* c) {
+    int rows = 0;
+    for (int ty = c->shard_rank; ty < c->tiles_y; ty += c->shard_world) rows += std::min(TILE, c->H - ty * TILE);
+    return rows;
+}
+
+int gs4d_set_tile_shard(gs4d_ctx* c, int rank, int world) {
+    if (!c) return GS4D_E_INVALID;
+    if (world < 1 || world > 1024 || rank < 0 || rank >= world) return fail(c, GS4D_E_INVALID, "set_tile_shard: need 0 <= rank < world <= 1024");
+    c->shard_rank = rank; c->shard_world = world;
+    return GS4D_OK;
+}
+
+int gs4d_band_rows(gs4d_ctx* c, int* rows) {
+    if (!c || !rows) return GS4D_E_INVALID;
+    *rows = band_pixel_rows(c);
+    return GS4D_OK;
+}
+
+int gs4d_read_band_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
+    if (!c || !dptr) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    const int rows = band_pixel_rows(c);
+    if (bytes != (size_t)rows * c->W * 4) return fail(c, GS4D_E_INVALID, "read_band_rgba8_device: bytes != band_rows*width*4");
+    int rc = resolve_image(c, c->cur_fb); if (rc) return rc;
+    rc = after_user_stream(c); if (rc) return rc;
+    rc = materialise_fb(c); if (rc) return rc;
+    Framebuffer& F = c->fbs[c->cur_fb];
+    rc = fb_access(c, F); if (rc) return rc;
+    Lane& L = lane(c);
+    HIPCHK(c, launch_pack_rgba8_band(L.s, F.mem, c->W, c->H, c->shard_rank, c->shard_world, rows, (uint32_t*)dptr));
+    if (c->user) {
+        HIPCHK(c, hipEventRecord(c->ev_readback, L.s));
+        HIPCHK(c, hipStreamWaitEvent(c->user, c->ev_readback, 0));
+    }
+    return GS4D_OK;
 }
 
 int gs4d_set_stream(gs4d_ctx* c, void* hip_stream) {

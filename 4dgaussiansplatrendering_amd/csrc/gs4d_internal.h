@@ -111,7 +111,7 @@ hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size
 void bin_scratch_free(BinScratch& b);
 // order == nullptr: instance k draws record k
 hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
-                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host);
+                          uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host, int shard_rank, int shard_world);
 hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pair_keys, size_t pair_cap, size_t ntiles);
 
 // ---- composite.hip ----
@@ -119,5 +119,7 @@ hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* 
                             int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb);
 hipError_t launch_fill(hipStream_t st, float4* fb, size_t npix, const float clear[4]);
 hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, size_t npix, uint32_t* out);
+// the pixel rows of the tile rows ty % world == rank, top of the band = the context's first tile row; band_rows pixel rows in all
+hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, int W, int H, int rank, int world, int band_rows, uint32_t* out);
 
 } // namespace gs4d

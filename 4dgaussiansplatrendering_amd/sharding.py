@@ -1,4 +1,6 @@
-"""Frame sharding for multi-GPU runs: independent frames of a camera/time sweep, one process per GPU.
+"""Sharding for multi-GPU runs, one process per GPU.  Primary mode: independent FRAMES of a camera/time sweep.
+Secondary mode, for one huge frame (config 5): rows of 8x8-pixel TILES dealt round-robin (gs4d_set_tile_shard); every rank generates
+keys and sorts all splats (the blend order is global), bins and composites only its own tile rows, and the bands are gathered.
 
 The reference is single-GPU and has no counterpart; the unit that shards is the frame (Application.cpp:145-190 renders one
 per loop iteration, each independent of the last).  No collective touches the data path: the only exchange is one gather of
@@ -24,3 +26,33 @@ def gather_frames(dist, frame, gathered, dst=0):
     """One gather of this step's frames (same-shaped tensors) to rank `dst`; `gathered` is a list of world tensors on dst, else None."""
     dist.gather(frame, gathered if dist.get_rank() == dst else None, dst=dst)
     return gathered
+
+
+# ---- single-frame sharding by tile rows -----------------------------------------------------------------------------------------
+TILE = 8
+
+
+def band_pixel_rows(rank, world, height):
+    """Framebuffer rows (bottom-up, like the framebuffer) of the tile rows ty % world == rank, in band order."""
+    rows = []
+    tiles_y = (height + TILE - 1) // TILE
+    for ty in range(rank, tiles_y, world):
+        rows.extend(range(ty * TILE, min(height, (ty + 1) * TILE)))
+    return rows
+
+
+def band_rows_max(world, height):
+    """Rows of the largest band (rank 0's): gathers need same-shaped tensors, shorter bands are padded at the end."""
+    return len(band_pixel_rows(0, world, height))
+
+
+def assemble_bands(bands, width, height, world):
+    """bands[r]: array-like of at least len(band_pixel_rows(r)) rows x width (x channels) -> the full frame."""
+    import numpy as np
+    first = np.asarray(bands[0])
+    out = np.zeros((height, width) + first.shape[2:], first.dtype)
+    for r in range(world):
+        rows = band_pixel_rows(r, world, height)
+        if rows:
+            out[rows] = np.asarray(bands[r])[:len(rows)]
+    return out

@@ -120,6 +120,14 @@ GS4D_API int gs4d_read_frame_rgba8_device(gs4d_ctx* ctx, int frames_back, void* 
  * work of that call — e.g. a kernel of the caller's that fills a buffer obtained with gs4d_buffer_device_ptr — and (b) whatever the
  * caller queues on it after a device read-back sees the pixels — e.g. an RCCL gather of the frames.  No host synchronisation. */
 GS4D_API int gs4d_set_stream(gs4d_ctx* ctx, void* hip_stream);
+/* Single-frame sharding over several GPUs (secondary mode; config 5): rows of 8x8-pixel tiles are dealt round-robin,
+ * tile row ty belongs to rank ty % world.  After gs4d_set_tile_shard(rank, world) a draw bins and composites only the context's own
+ * tile rows (every rank still generates keys and sorts all splats: the blend order is global); the other rows of its image keep the
+ * clear colour.  gs4d_read_band_rgba8_device packs the context's rows — band_rows pixel rows, its first tile row on top (bottom-up like
+ * the framebuffer) — for a gather; bytes == band_rows * width * 4.  rank 0 / world 1 restores the default. */
+GS4D_API int gs4d_set_tile_shard(gs4d_ctx* ctx, int rank, int world);
+GS4D_API int gs4d_band_rows(gs4d_ctx* ctx, int* rows);
+GS4D_API int gs4d_read_band_rgba8_device(gs4d_ctx* ctx, void* dptr, size_t bytes);
 GS4D_API int gs4d_finish(gs4d_ctx* ctx);                                          /* blocks until every lane is idle; reports device-side check failures */
 
 /* ---- measurement / test hooks ---- */

@@ -69,3 +69,34 @@ def test_round_robin_partition():
         assert seen == list(range(256))
         assert all(len(sh.frames_for_rank(256, r, world)) == 256 // world for r in range(world))
     assert sh.sweep_time(0, 256) == 0.0 and sh.sweep_time(255, 256) == 50.0
+
+
+def _band_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path[:0] = [HERE, ROOT]
+    sh = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h, w = 45, 24                                           # 6 tile rows, the last one 5 pixel rows high
+    full = (np.arange(h * w * 4, dtype=np.int64).reshape(h, w, 4) * 7 % 251).astype(np.uint8)      # what an unsharded render would be
+    rows = sh.band_pixel_rows(rank, world, h)
+    band = np.zeros((sh.band_rows_max(world, h), w, 4), np.uint8)                                   # padded to the common shape
+    band[:len(rows)] = full[rows]                                                                   # what this rank's GPU would pack
+    mine = torch.from_numpy(band)
+    gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+    sh.gather_frames(dist, mine, gathered, dst=0)
+    if rank == 0:
+        np.save(out, np.stack([sh.assemble_bands([g.numpy() for g in gathered], w, h, world), full]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_row_bands_reassemble(tmp_path, world):
+    """Single-frame sharding (secondary mode): bands of tile rows ty % world == rank, gathered and interleaved, are the frame."""
+    out = str(tmp_path / "bands.npy")
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_band_worker, args=(world, port, out), nprocs=world, join=True)
+    got, full = np.load(out)
+    assert np.array_equal(got, full)
+    sh = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
+    assert sorted(sum((sh.band_pixel_rows(r, world, 45) for r in range(world)), [])) == list(range(45))
