@@ -387,7 +387,7 @@ int alloc_fbs(gs4d_ctx* c, int w, int h) {
         c->fbs[i].is_clear = true; c->fbs[i].last_lane = -1;
     }
     c->W = w; c->H = h; c->tiles_x = (w + TILE - 1) / TILE; c->tiles_y = (h + TILE - 1) / TILE;
-    c->cur_fb = c->cur;
+    c->cur_fb = c->cur; c->prev_fb = -1;
     return GS4D_OK;
 }
 
