@@ -160,6 +160,12 @@ public:
     void SetUniform2f(const std::string&, float, float) {}
     void SetUniform3f(const std::string&, float, float, float) {}
     void SetUniform4f(const std::string&, float, float, float, float) {}
+    template <class V> void SetUniform2f(const std::string&, const V&) {}         // glm::vec2 / vec3 / vec4 overloads (Shader.h:47-59)
+    template <class V> void SetUniform3f(const std::string&, const V&) {}
+    template <class V> void SetUniform4f(const std::string&, const V&) {}
+    template <class M> void SetUniformMat3f(const std::string&, const M&) {}     // Shader.h:64-68
+    template <class M> void SetUniformMat2f(const std::string&, const M&) {}
+    static bool TryCompile(const std::string&, ShaderType) { return true; }      // no GLSL is compiled on this path
     int Mode() const { return m_mode; }
 private:
     int m_mode = -1;
@@ -234,8 +240,15 @@ public:
     template <class V> Camera(int width, int height, const V& p, const V& o) : position(p[0], p[1], p[2]), orientation(o[0], o[1], o[2]), mWidth(width), mHeight(height) {}
     gs4d::compat::mat4 GetViewMatrix() { gs4d::compat::mat4 m; gs4d_host_look_at(&position.x, &orientation.x, &up.x, &m.m[0][0]); return m; }
     gs4d::compat::mat4 GetProjMatrix() { gs4d::compat::mat4 m; gs4d_host_perspective(mFOV, mWidth, mHeight, mNear, mFar, &m.m[0][0]); return m; }
+    // glm::mat4 operator*: Result[c] = sum_k A[k] * B[c][k], summed left to right (type_mat4x4.inl), A = proj, B = view (Camera.cpp:45-48)
+    gs4d::compat::mat4 GetViewProjMatrix() {
+        const gs4d::compat::mat4 P = GetProjMatrix(), V = GetViewMatrix(); gs4d::compat::mat4 R;
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) R.m[c][r] = ((P.m[0][r] * V.m[c][0] + P.m[1][r] * V.m[c][1]) + P.m[2][r] * V.m[c][2]) + P.m[3][r] * V.m[c][3];
+        return R;
+    }
     gs4d::compat::vec3 GetPosition() { return position; }
     float GetFar() { return mFar; } float GetNear() { return mNear; } float GetFOV() { return mFOV; }
+    float GetScreenWidth() { return (float)mWidth; } float GetScreenHeight() { return (float)mHeight; }
     void SetNear(float v) { mNear = v; } void SetFar(float v) { mFar = v; } void SetFOV(float v) { mFOV = v; }
     void SetWidth(int w) { mWidth = w; } void SetHeight(int h) { mHeight = h; }
     void Resize(int w, int h) { mWidth = w; mHeight = h; }
