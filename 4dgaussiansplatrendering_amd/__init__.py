@@ -42,6 +42,7 @@ def _load():
         "gs4d_buffer_read": (i32, [vp, u32, sz, vp, sz]),
         "gs4d_buffer_destroy": (i32, [vp, u32]),
         "gs4d_buffer_device_ptr": (i32, [vp, u32, C.POINTER(vp), C.POINTER(sz)]),
+        "gs4d_buffer_invalidate": (i32, [vp, u32]),
         "gs4d_bind_storage": (i32, [vp, i32, u32]),
         "gs4d_set_mode": (i32, [vp, i32]),
         "gs4d_set_uniform_1f": (i32, [vp, i32, f32]),
@@ -314,6 +315,10 @@ class Context:
         self._chk(_lib.gs4d_buffer_device_ptr(self._h, buf, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def invalidate(self, buf):
+        """Before overwriting a buffer through its device pointer on the caller's stream (gs4d_buffer_invalidate)."""
+        self._chk(_lib.gs4d_buffer_invalidate(self._h, buf))
+
     def bind(self, slot, buf):
         self._chk(_lib.gs4d_bind_storage(self._h, slot, buf))
 
@@ -419,7 +424,8 @@ class Context:
         st = np.zeros(8, np.uint64)
         self._chk(_lib.gs4d_get_stats(self._h, _ptr(st)))
         return {"entries": int(st[0]), "capacity": int(st[1]), "reruns": int(st[2]), "tiles": int(st[3]),
-                "depth_sort_passes": int(st[4]), "tile_sort_passes": int(st[5]), "lanes": int(st[6])}
+                "depth_sort_passes": int(st[4]), "tile_sort_passes": int(st[5]), "lanes": int(st[6]),
+                "unordered_draws": int(st[7]) & 0xFFFFFFFF, "longest_list": int(st[7]) >> 32}
 
     def debug_projected(self, n):
         out = np.empty((n, 16), np.float32)

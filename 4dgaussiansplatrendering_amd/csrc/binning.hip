@@ -73,8 +73,13 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
                                                           unsigned long long* status, unsigned long long* gstatus, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
                                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
-                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base, int dbg,
+                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base, int dbg_arg,
                                                           uint32_t shard_rank, uint32_t shard_world /* tile row ty is ours iff ty % shard_world == shard_rank */) {
+#ifdef GS4D_TUNING
+    const int dbg = dbg_arg;             // ablation bits (GS4D_EMIT_DBG): tuning builds only (make TUNING=1)
+#else
+    constexpr int dbg = 0; (void)dbg_arg;
+#endif
     __shared__ uint32_t wsum[BIN_WAVES];
     __shared__ unsigned long long s_prefix;
     __shared__ uint32_t s_blk;
@@ -243,7 +248,11 @@ void bin_scratch_free(BinScratch& b) {
 hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
                           uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host, int shard_rank, int shard_world) {
     (void)tiles_y;
+#ifdef GS4D_TUNING
     static const int dbg = getenv("GS4D_EMIT_DBG") ? atoi(getenv("GS4D_EMIT_DBG")) : 0;      // tuning aid (ablation): 1 no rect gather, 2 no histogram, 4 no writes
+#else
+    const int dbg = 0;
+#endif
     if (++b.epoch >= (1u << 22)) {            // epoch wrap: forget every old word
         hipError_t e = hipMemsetAsync(b.status, 0, (b.block_cap + b.block_cap / 64 + 2) * 8, st);
         if (e != hipSuccess) return e;

@@ -1,0 +1,149 @@
+// composite2.hip — compositing kernel of the unordered draw path: one wave64 per 8x8 tile, the tile's list is ORDERED HERE.
+//
+// Same arithmetic contract as composite.hip (rasteriser Geometry.h:44-50 / Renderer.cpp:33-39, fragment shaders
+// Shader/Splats4D/Splat4DFragShader.GLSL:16-31 and the 3D/2D variants, blend Application.cpp:150-154): the chunk walk is the shared
+// composite_chunk().  What differs is where the blend order comes from.  tilelist.hip leaves every tile an UNORDERED list of
+// (key, record) entries; "instance order" — the order the reference's ROP blends in — is ascending (key, record) (KeySrc,
+// gs4d_internal.h).  The wave reads its whole list into registers (PER entries per lane; k_tilescan guarantees it fits, otherwise the
+// draw was aborted and re-run on the ordered path), sorts it with a wave-local LSD radix sort over 6-bit digits — 64 counters, one
+// per lane — and then walks it from the end (front-most) as composite.hip does.
+//
+// Radix pass, one wave, no other wave to wait for: count the digit with no-return LDS atomics, exclusive wave scan of the 64
+// counters, then a RETURNING LDS atomic add on the digit's running position gives every element its slot.  That is stable because
+// (a) the LDS unit serialises the lanes of one instruction that hit the same counter in ascending lane order — verified on the device
+// at context creation (lds_atomic_order_selftest; the unordered path is not used if the test fails) — and (b) a wave's LDS
+// instructions execute in program order, so element j*64+lane is ranked before element (j+1)*64+lane'.  Digits on which every key of
+// the list agrees are skipped.  Keys that tie are rare (24-bit depth keys, tens of entries): the list is sorted on the key alone and
+// checked for equal neighbours; only then is it sorted on the record index first and on the key again.
+#include "composite_common.h"
+
+namespace gs4d {
+
+template <int PER>
+struct WaveSort {
+    uint32_t k[PER], r[PER];
+
+    __device__ __forceinline__ void pass(bool on_rec, int shift, uint32_t E, uint32_t* ek, uint32_t* er, uint32_t* cnt, uint32_t lane) {
+        cnt[lane] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if ((uint32_t)j * 64u >= E) break;                                     // uniform
+            if ((uint32_t)j * 64u + lane < E) { const uint32_t d = ((on_rec ? r[j] : k[j]) >> shift) & 63u; __hip_atomic_fetch_add(&cnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        }
+        __syncthreads();
+        const uint32_t c = cnt[lane];
+        if (__ballot(c == E) != 0ull) return;                                      // uniform: one digit holds every key — a stable identity
+        uint32_t inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += t; }
+        cnt[lane] = inc - c;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if ((uint32_t)j * 64u >= E) break;
+            if ((uint32_t)j * 64u + lane < E) {
+                const uint32_t d = ((on_rec ? r[j] : k[j]) >> shift) & 63u;
+                const uint32_t dest = atomicAdd(&cnt[d], 1u);                      // lane-ordered within the instruction, program-ordered across j
+                ek[dest] = k[j]; er[dest] = r[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            if ((uint32_t)j * 64u >= E) break;
+            if ((uint32_t)j * 64u + lane < E) { k[j] = ek[j * 64 + lane]; r[j] = er[j * 64 + lane]; }
+        }
+        __syncthreads();
+    }
+};
+
+template <bool PREMULT_C, int PER>
+__global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart,
+                                                     const uint32_t* __restrict__ total, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
+                                                     float4* __restrict__ fb, int key_passes, int rec_passes) {
+    __shared__ float4 stage[64 * 3];
+    __shared__ uint32_t pmask[64 * 2];
+    __shared__ uint32_t cnt[64];
+    __shared__ uint32_t ek[64 * PER];
+    __shared__ uint32_t er[64 * PER];
+    if (total[1]) return;                                   // aborted draw (capacity or list length): the host re-runs it
+    const uint32_t tile = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE;
+    const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
+    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+    const uint32_t start = tstart[tile];
+    const uint32_t E = min(tstart[tile + 1] - start, (uint32_t)(64 * PER));      // k_tilescan guarantees the bound; min() keeps a broken promise inside LDS
+
+    if (E > 1u) {
+        WaveSort<PER> ws;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            ws.k[j] = 0u; ws.r[j] = 0u;
+            if ((uint32_t)j * 64u + lane < E) { const uint2 e = entries[start + j * 64 + lane]; ws.k[j] = e.x; ws.r[j] = e.y; }
+        }
+        for (int p = 0; p < key_passes; ++p) ws.pass(false, 6 * p, E, ek, er, cnt, lane);
+        // the sorted keys go to LDS for the neighbour test (the last pass may have been an identity that wrote nothing)
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { if ((uint32_t)j * 64u + lane < E) { ek[j * 64 + lane] = ws.k[j]; er[j * 64 + lane] = ws.r[j]; } }
+        __syncthreads();
+        bool tie = false;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { const uint32_t i = (uint32_t)j * 64u + lane; if (i + 1u < E) tie |= ek[i] == ek[i + 1u]; }
+        if (__ballot(tie) != 0ull) {                        // equal keys: instance order among them is ascending record index
+            __syncthreads();
+            for (int p = 0; p < rec_passes; ++p) ws.pass(true, 6 * p, E, ek, er, cnt, lane);
+            for (int p = 0; p < key_passes; ++p) ws.pass(false, 6 * p, E, ek, er, cnt, lane);
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { if ((uint32_t)j * 64u + lane < E) er[j * 64 + lane] = ws.r[j]; }
+        }
+        __syncthreads();
+    } else if (E == 1u) {
+        if (lane == 0) er[0] = entries[start].y;
+        __syncthreads();
+    }
+
+    float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
+    for (uint32_t hi = E; hi > 0u;) {
+        const uint32_t c = min(64u, hi);
+        const uint32_t rec = lane < c ? er[hi - 1u - lane] : 0u;       // lane s holds list entry hi-1-s : s = 0 is the front-most of the chunk
+        composite_chunk<PREMULT_C>(proj, rec, c, lane, tx0, ty0, fx, fy, stage, pmask, 0, T, Cr, Cg, Cb, A);
+        hi -= c;
+        if (__ballot(T > 0.0f) == 0ull) break;              // exact: every remaining contribution is multiplied by T == 0
+    }
+    if (px < W && py < H) {
+        const size_t o = (size_t)py * W + px;
+        const float4 d = fb_is_clear ? clear : fb[o];
+        fb[o] = make_float4(Cr + T * d.x, Cg + T * d.y, Cb + T * d.z, A + T * d.w);
+    }
+}
+
+template <bool PREMULT_C>
+static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* total, int tiles_x, int W, int H,
+                            int fb_is_clear, float4 c, float4* fb, int kp, int rp) {
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp)
+    switch (per) {
+    case 1: GS4D_V2(1); break;
+    case 2: GS4D_V2(2); break;
+    case 4: GS4D_V2(4); break;
+    case 8: GS4D_V2(8); break;
+    case 16: GS4D_V2(16); break;
+    default: GS4D_V2(32); break;
+    }
+#undef GS4D_V2
+    return hipGetLastError();
+}
+
+hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
+                               int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits) {
+    if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
+    int per = 1; while ((uint32_t)per * 64u < hint) per *= 2;
+    const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
+    const dim3 grid((unsigned)(tiles_x * tiles_y));
+    const int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
+    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp)
+                     : launch_v2<false>(st, per, grid, proj, entries, tstart, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp);
+}
+
+} // namespace gs4d

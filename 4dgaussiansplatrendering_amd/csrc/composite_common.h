@@ -1,0 +1,116 @@
+// composite_common.h — what the two compositing kernels (composite.hip: ordered lists; composite2.hip: lists ordered in LDS) share.
+#pragma once
+#include "gs4d_internal.h"
+
+namespace gs4d {
+
+// One chunk of <= 64 list entries is processed in one of two ways (wave-uniform choice):
+//  * splat-parallel (small footprints, the 10^6..10^7-splat cube configs: a quad covers ~3 of the tile's 64 pixels):
+//      phase A, lane = entry: evaluates the coverage rule only for the pixels of its own bounding box inside the tile and ORs its
+//               bit into the per-pixel hit masks in LDS;
+//      phase B, lane = pixel: walks the set bits of its own mask front to back, fetches that entry from LDS and blends.
+//      Work is proportional to the number of covered pixels instead of 64 x entries.
+//  * pixel-parallel broadcast (large footprints, e.g. the teapot scenes): every lane tests every entry of the chunk.
+// Entries whose box covers more than SMALL_AREA pixels of the tile are always tested pixel-parallel.
+constexpr int SMALL_AREA = 16;
+
+template <bool PREMULT_C>
+__device__ __forceinline__ void blend_fragment(float u, float v, float alpha, float r_, float g_, float b_, float& T, float& Cr, float& Cg, float& Cb, float& A) {
+    const float q = u * u + v * v;
+    const float cg = __expf(-32.0f * q);
+    if (cg >= 0.0001f) {                                   // Splat4DFragShader.GLSL:30 discard
+        const float al = alpha * cg;
+        const float w = T * al;
+        if (PREMULT_C) { r_ *= cg; g_ *= cg; b_ *= cg; }   // Splat3DFragShaderFull.GLSL:22
+        Cr += w * r_; Cg += w * g_; Cb += w * b_; A += w * al;
+        T *= (1.0f - al);
+    }
+}
+
+// One chunk of the tile's list, front to back: lane s < cnt carries record `rec` of list entry (end of chunk - 1 - s), so s = 0 is the
+// front-most entry.  stage: 64 x 3 float4, pmask: 64 x 2 words (per pixel: 64-bit mask of the chunk entries that cover it).
+template <bool PREMULT_C>
+__device__ __forceinline__ void composite_chunk(const float4* __restrict__ proj, uint32_t rec, uint32_t cnt, uint32_t lane, int tx0, int ty0, float fx, float fy,
+                                                float4* stage, uint32_t* pmask, int dbg, float& T, float& Cr, float& Cg, float& Cb, float& A) {
+    // lane s holds list entry hi-1-s : s = 0 is the LAST (front-most) entry of this chunk
+    int lx0 = 0, ly0 = 0, bw = 0, area = 0;
+    float4 ra = make_float4(0, 0, 0, 0), rb = ra;
+    if (lane < cnt) {
+        const float4* r = proj + (size_t)rec * 4;
+        ra = r[0]; rb = r[1];
+        const float4 rc = r[2];
+        stage[lane * 3 + 0] = ra;
+        stage[lane * 3 + 1] = rb;
+        stage[lane * 3 + 2] = rc;
+        const uint32_t r0 = __float_as_uint(rc.z), r1 = __float_as_uint(rc.w);
+        lx0 = max((int)(r0 & 0xFFFFu) - tx0, 0); ly0 = max((int)(r0 >> 16) - ty0, 0);
+        const int lx1 = min((int)(r1 & 0xFFFFu) - tx0, TILE - 1), ly1 = min((int)(r1 >> 16) - ty0, TILE - 1);
+        bw = lx1 - lx0 + 1;
+        const int bh = ly1 - ly0 + 1;
+        area = (bw > 0 && bh > 0) ? bw * bh : 0;
+    }
+    const bool big = area > SMALL_AREA;
+    const uint64_t bigmask = __ballot(big);
+    pmask[lane * 2] = 0u; pmask[lane * 2 + 1] = 0u;
+    __syncthreads();
+    if (dbg != 2 && (dbg == 1 || (uint32_t)__popcll(bigmask) * 2u > cnt)) {
+        // ---- pixel-parallel broadcast over the whole chunk ----
+        for (uint32_t s = 0; s < cnt; ++s) {
+            const float4 a = stage[s * 3 + 0];          // cx, cy, a0x, a0y      (uniform address: LDS broadcast)
+            const float4 b = stage[s * 3 + 1];          // a1x, a1y, alpha, r
+            const float dx = __fsub_rn(fx, a.x), dy = __fsub_rn(fy, a.y);
+            const float u = __fmaf_rn(a.z, dx, __fmul_rn(a.w, dy));
+            const float v = __fmaf_rn(b.x, dx, __fmul_rn(b.y, dy));
+            const bool cov = fabsf(u) <= 0.5f && fabsf(v) <= 0.5f;
+            if (__ballot(cov) == 0ull) continue;
+            const float4 c = stage[s * 3 + 2];          // g, b, -, -
+            if (cov) blend_fragment<PREMULT_C>(u, v, b.z, b.w, c.x, c.y, T, Cr, Cg, Cb, A);
+        }
+    } else {
+        // ---- phase A (lane = entry): mark the covered pixels of small footprints ----
+        const int small_area = big ? 0 : area;
+        int ix = 0, iy = 0;
+        for (int k = 0; k < SMALL_AREA; ++k) {
+            const bool act = k < small_area;
+            if (__ballot(act) == 0ull) break;
+            if (act) {
+                const int qx = lx0 + ix, qy = ly0 + iy;
+                const float dx = __fsub_rn((float)(tx0 + qx) + 0.5f, ra.x), dy = __fsub_rn((float)(ty0 + qy) + 0.5f, ra.y);
+                const float u = __fmaf_rn(ra.z, dx, __fmul_rn(ra.w, dy));
+                const float v = __fmaf_rn(rb.x, dx, __fmul_rn(rb.y, dy));
+                if (fabsf(u) <= 0.5f && fabsf(v) <= 0.5f) atomicOr(&pmask[(qy * TILE + qx) * 2 + (int)(lane >> 5)], 1u << (lane & 31u));
+                if (++ix == bw) { ix = 0; ++iy; }
+            }
+        }
+        // ---- large footprints of this chunk: every pixel tests them itself ----
+        uint64_t mine = 0ull;
+        for (uint64_t bm = bigmask; bm; bm &= bm - 1ull) {
+            const int e = __ffsll((long long)bm) - 1;
+            const float4 a = stage[e * 3 + 0];
+            const float4 b = stage[e * 3 + 1];
+            const float dx = __fsub_rn(fx, a.x), dy = __fsub_rn(fy, a.y);
+            const float u = __fmaf_rn(a.z, dx, __fmul_rn(a.w, dy));
+            const float v = __fmaf_rn(b.x, dx, __fmul_rn(b.y, dy));
+            if (fabsf(u) <= 0.5f && fabsf(v) <= 0.5f) mine |= 1ull << e;
+        }
+        __syncthreads();
+        // ---- phase B (lane = pixel): blend the entries that hit this pixel, front to back ----
+        uint64_t m = mine | (uint64_t)pmask[lane * 2] | ((uint64_t)pmask[lane * 2 + 1] << 32);
+        while (__ballot(m != 0ull) != 0ull) {
+            if (m != 0ull) {
+                const int e = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const float4 a = stage[e * 3 + 0];
+                const float4 b = stage[e * 3 + 1];
+                const float4 c = stage[e * 3 + 2];
+                const float dx = __fsub_rn(fx, a.x), dy = __fsub_rn(fy, a.y);
+                const float u = __fmaf_rn(a.z, dx, __fmul_rn(a.w, dy));
+                const float v = __fmaf_rn(b.x, dx, __fmul_rn(b.y, dy));
+                blend_fragment<PREMULT_C>(u, v, b.z, b.w, c.x, c.y, T, Cr, Cg, Cb, A);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+} // namespace gs4d

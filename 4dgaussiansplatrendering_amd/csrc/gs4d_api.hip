@@ -18,6 +18,7 @@
 #include "gs4d_internal.h"
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <algorithm>
 #include <cmath>
@@ -44,6 +45,11 @@ struct Buffer {
     unsigned tail_mask = 0;        // lanes whose other kernels (key generation) have read it since that write (their tail event does)
     uint64_t touch = 0;            // context op counter at the last device-side use (host writes compare it with the last full sync)
     bool alive = false;
+    // Provenance of a sort index: set when gs4d_sort_pairs has sorted exactly the keys and the identity index gs4d_keygen wrote for
+    // `prov_data` — the contents are then "records of prov_data in ascending (depth key, record index)" for as long as `version`
+    // still equals prov_ver, and a draw that binds it can take its blend order from the keys instead of reading it (tilelist.hip).
+    bool prov_valid = false; gs4d_buf prov_data = 0; uint64_t prov_data_ver = 0, prov_ver = 0; size_t prov_n = 0; int prov_bits = 32;
+    KeySrc prov_ks;
 };
 
 struct DrawArgs {
@@ -54,6 +60,8 @@ struct DrawArgs {
     bool quads = false;
     bool fb_was_clear = false;     // framebuffer state the composite of this draw must start from (kept for a re-run)
     int lane = 0, fb = 0;          // where the draw ran
+    bool v2 = false;               // unordered tile lists (tilelist.hip); false: instance-ordered lists (binning.hip)
+    KeySrc ks; int keybits = 32;   // v2: where the blend order comes from
 };
 
 struct Framebuffer {
@@ -68,13 +76,15 @@ struct Lane {
     hipEvent_t ev_tail = nullptr;      // recorded when the lane is left: everything queued on it so far
     bool drawn = false;                // the lane's current frame has a draw in it: the next frame-starting call moves on
     float4* proj = nullptr; uint2* rects = nullptr; size_t proj_cap = 0, proj_n = 0;   // projected records (64 B) and their pixel rectangles
-    uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;
+    uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;   // tile-list entries: one allocation of 8 * pair_cap bytes — (tile ids | records) on the ordered path, (key, record) pairs on the unordered one
+    TileLists tl;                      // unordered path: per-tile counts / starts / cursors, per-record blend keys
     uint32_t* order_copy = nullptr; size_t order_cap = 0;   // private copy of the last draw's sort index (for a re-run after overflow)
     SortScratch depth_sort, pair_sort;
     BinScratch bin;
     uint32_t* host_total = nullptr;     // pinned + mapped: [0..3] the binning total of the last draw, [4] the error word kernels raise
     uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
     gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
+    gs4d_buf kg_idx = 0, kg_data = 0; uint64_t kg_idx_ver = 0, kg_data_ver = 0; KeySrc kg_ks; int kg_bits = 32;   // ... the identity index it wrote beside them, and what the keys were computed from
     bool pending = false;              // the lane's last draw has not had its tile-list capacity validated yet
     DrawArgs pending_args;
 };
@@ -104,6 +114,12 @@ struct gs4d_ctx {
     int shard_rank = 0, shard_world = 1;   // single-frame sharding: this context bins and composites the tile rows ty % world == rank
     int prev_fb = -1;                  // the image the last gs4d_clear moved away from (still intact until its lane comes round again)
     uint64_t stat_entries = 0, stat_reruns = 0, stat_depth_passes = 0, stat_tile_passes = 0;
+    // draw path selection: the unordered path needs lists short enough to be sorted in LDS (<= V2_MAX_LIST entries per tile)
+    int path_pref = 0;                 // GS4D_DRAW_PATH: 0 auto, 1 ordered path only, 2 = auto (kept for symmetry)
+    bool long_lists = false;           // the last unordered draw met a list longer than V2_MAX_LIST: draws use the ordered path ...
+    uint64_t ordered_draws = 0;        // ... and probe the unordered one again every so often when the lists look short on average
+    uint32_t list_hint = 256;          // LDS list capacity the compositor is launched with (64 << k); grows on demand, validated per draw on the device
+    uint64_t stat_v2_draws = 0, stat_longest = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
     static constexpr int PROF_FRAMES = 128;
     unsigned profiling = 0;                    // bit s set: stage s is timed
@@ -131,7 +147,7 @@ Lane& lane(gs4d_ctx* c) { return c->lanes[c->cur]; }
 
 struct StageTimer {
     gs4d_ctx* c; int slot; hipStream_t s;
-    StageTimer(gs4d_ctx* c_, int id) : c(c_), slot(-1), s(c_->lanes[c_->cur].s) {
+    StageTimer(gs4d_ctx* c_, int id) : c(c_), slot(-1), s(c_->lanes[c_->cur].s) {      // run_draw re-runs make their lane current first (resolve_lane)
         if (((c->profiling >> id) & 1u) && c->prof_frame < gs4d_ctx::PROF_FRAMES && c->prof_tick % (uint64_t)c->prof_every == 0) { slot = c->prof_frame * GS4D_T_COUNT + id; (void)hipEventRecord(c->ev0[slot], s); }
     }
     ~StageTimer() { if (slot >= 0) { (void)hipEventRecord(c->ev1[slot], s); c->ran[slot] = 1; } }
@@ -167,7 +183,15 @@ int after_user_stream(gs4d_ctx* c) {
 // The current lane is about to read (or overwrite) buffer B with a kernel: order it after the other lanes' kernels that wrote B
 // (or, for a write, still read it).  Device-side waits only.  A lane other than the current one has been left since it last touched
 // B, so its tail event (recorded on leaving) covers that use; a draw's reads are already covered by its binning-done event.
+int resolve_lane(gs4d_ctx* c, int li);
 int lane_access(gs4d_ctx* c, Buffer& B, bool write) {
+    if (write) {
+        // An unordered draw never read its sort index — but if its validation fails it is re-run on the ordered path, which does.
+        // Validate such draws before the index they were given is overwritten (in steady state their event completed long ago).
+        const gs4d_buf id = (gs4d_buf)(&B - c->bufs.data());
+        for (int i = 0; i < c->nlanes; ++i)
+            if (c->lanes[i].pending && c->lanes[i].pending_args.v2 && c->lanes[i].pending_args.order == id) { int rc = resolve_lane(c, i); if (rc) return rc; }
+    }
     Lane& L = lane(c);
     const unsigned me = 1u << c->cur;
     if (B.wr_lane >= 0 && B.wr_lane != c->cur && !(B.ordered_mask & me)) {
@@ -193,10 +217,9 @@ int ensure_pairs(gs4d_ctx* c, Lane& L, size_t cap) {
     if (L.pair_cap >= cap) return GS4D_OK;
     HIPCHK(c, hipStreamSynchronize(L.s));
     if (L.pair_keys) (void)hipFree(L.pair_keys);
-    if (L.pair_vals) (void)hipFree(L.pair_vals);
     L.pair_keys = L.pair_vals = nullptr; L.pair_cap = 0;
-    HIPCHK(c, hipMalloc(&L.pair_keys, cap * 4));
-    HIPCHK(c, hipMalloc(&L.pair_vals, cap * 4));
+    HIPCHK(c, hipMalloc(&L.pair_keys, cap * 8));
+    L.pair_vals = L.pair_keys + cap;
     L.pair_cap = cap;
     return GS4D_OK;
 }
@@ -270,6 +293,25 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, 
     return GS4D_OK;
 }
 
+// Unordered path: the projection kernel has counted the entries per tile; scan, scatter, composite (tilelist.hip, composite2.hip).
+int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, size_t nrecords, int premult_c) {
+    const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    {
+        StageTimer t(c, GS4D_T_BINNING);
+        HIPCHK(c, launch_tilescan(L.s, L.tl, ntiles, L.bin.total, L.host_total_dev, L.pair_cap, c->list_hint));
+        HIPCHK(c, hipEventRecord(L.ev_emit, L.s));     // totals, flags and the longest list are in pinned host memory behind this event
+        HIPCHK(c, launch_tile_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, (uint2*)L.pair_keys, c->tiles_x, c->shard_rank, c->shard_world));
+    }
+    c->stat_tile_passes = 0;
+    {
+        StageTimer t(c, GS4D_T_COMPOSITE);
+        int recbits = 1; while (recbits < 32 && ((size_t)1 << recbits) < nrecords) ++recbits;
+        HIPCHK(c, launch_composite_v2(L.s, L.proj, (const uint2*)L.pair_keys, L.tl.tstart, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, c->clear, F.mem,
+                                      c->list_hint, a.keybits, recbits));
+    }
+    return GS4D_OK;
+}
+
 // `preprocess` false: the re-run of a draw whose tile lists overflowed (projected records and the sort-index copy are still valid).
 int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     Lane& L = c->lanes[a.lane];
@@ -294,6 +336,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
+    if (a.v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
     uint32_t* order_copy = nullptr;
     if (order) {
         if (L.order_cap < a.instances) {
@@ -317,13 +360,15 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
         }
         if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
         { int rc = lane_access(c, *data, false); if (rc) return rc; data->rd_mask |= 1u << a.lane; }
-        if (ob) { int rc = lane_access(c, *ob, false); if (rc) return rc; ob->rd_mask |= 1u << a.lane; }
+        if (ob && !a.v2) { int rc = lane_access(c, *ob, false); if (rc) return rc; ob->rd_mask |= 1u << a.lane; }
         {
             StageTimer t(c, GS4D_T_PREPROCESS);
             const PreOut po = { L.proj, L.rects };
-            if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po));
-            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po));
-            else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, npre, a.u, c->W, c->H, po));
+            TileCount tc;
+            if (a.v2) { tc.tcount = L.tl.tcount; tc.skey = L.tl.skey; tc.tiles_x = c->tiles_x; tc.shard_rank = c->shard_rank; tc.shard_world = c->shard_world; tc.ks = a.ks; }
+            if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
+            else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
+            else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, npre, a.u, c->W, c->H, po, tc));
         }
         L.proj_n = npre;
         { int rc = fb_access(c, F); if (rc) return rc; }
@@ -331,6 +376,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
     if (L.pair_cap < want) { int rc = ensure_pairs(c, L, want); if (rc) return rc; }
+    if (a.v2) return enqueue_raster_v2(c, L, F, a, npre, premult);
     return enqueue_raster(c, L, F, order, order_copy, a.instances, npre, premult, a.fb_was_clear);
 }
 
@@ -340,17 +386,30 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
 int resolve_lane(gs4d_ctx* c, int li) {
     Lane& L = c->lanes[li];
     while (L.pending) {
-        HIPCHK(c, hipEventSynchronize(L.ev_emit));     // the entry count is final once the binning kernel has run
+        HIPCHK(c, hipEventSynchronize(L.ev_emit));     // the entry count is final once the binning kernel (ordered path) / the tile scan (unordered path) has run
         L.pending = false;
         if (L.host_total[4]) return fail(c, GS4D_E_DEVICE, DEVICE_CHECK_MSG);
         const uint64_t total = (uint64_t)L.host_total[2] | ((uint64_t)L.host_total[3] << 32);
-        if (!L.host_total[1]) { c->stat_entries = total; break; }
+        const uint32_t flags = L.host_total[1];
+        if (L.pending_args.v2) c->stat_longest = L.host_total[5];
+        if (!flags) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)");
         c->stat_reruns++;
+        c->stat_entries = total;
+        const bool was_v2 = L.pending_args.v2;     // an unordered draw kept no copy of its sort index: whatever path the re-run takes, it starts from the projection
+        if (L.pending_args.v2 && (flags & 2u)) {
+            // a list longer than the compositor was launched for: grow the LDS list capacity, or leave the unordered path
+            const uint32_t longest = L.host_total[5];
+            if (longest > V2_MAX_LIST) { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; }
+            else { while (c->list_hint < longest + longest / 4u && c->list_hint < V2_MAX_LIST) c->list_hint *= 2u; if (c->list_hint < longest) c->list_hint = V2_MAX_LIST; }
+        }
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;
-        c->stat_entries = total;
-        rc = run_draw(c, L.pending_args, false);
+        // the re-run goes to the draw's own lane: make it current while its kernels are queued
+        const int saved = c->cur;
+        c->cur = li;
+        rc = run_draw(c, L.pending_args, was_v2);
+        c->cur = saved;
         if (rc) return rc;
         L.pending = true;
     }
@@ -414,6 +473,7 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     memset(&c->u, 0, sizeof c->u);
     for (int i = 0; i < 4; ++i) c->u.view[5 * i] = c->u.proj[5 * i] = 1.0f;
     if (const char* ev = getenv("GS4D_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) c->nlanes = v; }     // tuning knob
+    if (const char* ev = getenv("GS4D_DRAW_PATH")) { if (!strcmp(ev, "ordered")) c->path_pref = 1; }                         // test hook: instance-ordered tile lists for every draw
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
     for (int i = 0; i < c->nlanes; ++i) {
         Lane& L = c->lanes[i];
@@ -431,7 +491,10 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
     }
     { bool ordered = false; if ((e = lds_atomic_order_selftest(c->lanes[0].s, &ordered)) != hipSuccess) return bail(hipfail(c, e, "lds_atomic_order_selftest")); c->atomic_rank = ordered; }
-    for (int i = 0; i < c->nlanes; ++i) c->lanes[i].depth_sort.atomic_rank = c->lanes[i].pair_sort.atomic_rank = c->atomic_rank;
+    const int shape_knob = getenv("GS4D_SORT_SHAPE") ? atoi(getenv("GS4D_SORT_SHAPE")) : 0, rank_knob = getenv("GS4D_SORT_RANK") ? atoi(getenv("GS4D_SORT_RANK")) : 0;
+    for (int i = 0; i < c->nlanes; ++i) {
+        for (SortScratch* ss : { &c->lanes[i].depth_sort, &c->lanes[i].pair_sort }) { ss->atomic_rank = c->atomic_rank; ss->shape_knob = shape_knob; ss->rank_knob = rank_knob; }
+    }
     int rc = alloc_fbs(c, width, height);
     if (rc) return bail(rc);
     *out = c;
@@ -450,7 +513,7 @@ void gs4d_destroy(gs4d_ctx* c) {
         if (L.proj) (void)hipFree(L.proj);
         if (L.rects) (void)hipFree(L.rects);
         if (L.pair_keys) (void)hipFree(L.pair_keys);
-        if (L.pair_vals) (void)hipFree(L.pair_vals);
+        tile_lists_free(L.tl);
         sort_scratch_free(L.depth_sort); sort_scratch_free(L.pair_sort); bin_scratch_free(L.bin);
         if (L.host_total) (void)hipHostFree(L.host_total);
         if (L.ev_emit) (void)hipEventDestroy(L.ev_emit);
@@ -545,6 +608,26 @@ int gs4d_buffer_device_ptr(gs4d_ctx* c, gs4d_buf b, void** dptr, size_t* bytes) 
     return GS4D_OK;
 }
 
+int gs4d_buffer_invalidate(gs4d_ctx* c, gs4d_buf b) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    Buffer* B = getbuf(c, b);
+    if (!B) return fail(c, GS4D_E_INVALID, "buffer_invalidate: bad buffer name");
+    int rc = resolve_pending(c); if (rc) return rc;           // a draw that has to be re-run reads the old contents: settle those first
+    if (B->touch > c->synced) {
+        if (c->user) {
+            // the caller's stream waits for everything queued on the lanes so far (a superset of the kernels that use this buffer)
+            for (int i = 0; i < c->nlanes; ++i) {
+                HIPCHK(c, hipEventRecord(c->lanes[i].ev_tail, c->lanes[i].s));
+                HIPCHK(c, hipStreamWaitEvent(c->user, c->lanes[i].ev_tail, 0));
+            }
+        } else { rc = sync_all(c); if (rc) return rc; }
+    }
+    B->version++;                                             // SoA shadow, key bounds, histogram hand-off and sort-index provenance all compare against it
+    B->prov_valid = false;
+    return GS4D_OK;
+}
+
 int gs4d_bind_storage(gs4d_ctx* c, int slot, gs4d_buf b) {
     if (!c) return GS4D_E_INVALID;
     if (slot < 0 || slot >= 8) return fail(c, GS4D_E_INVALID, "bind_storage: slot out of range");
@@ -612,9 +695,13 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     const bool have_hist = L.depth_sort.hist_pending && keys == L.kg_buf && K->version == L.kg_ver && n == L.kg_n;
     const int key_bits = have_hist ? L.depth_sort.hist_bits : 32;
     c->stat_depth_passes = (uint64_t)std::max(2, (key_bits + 7) / 8);
+    // ... and when the payload is the identity index the same call wrote, the sorted payload is "the records in ascending (key, index)"
+    const bool identity_payload = have_hist && vals == L.kg_idx && V->version == L.kg_idx_ver;
     StageTimer t(c, GS4D_T_SORT);
     HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, key_bits, have_hist));
     K->version++; V->version++;
+    V->prov_valid = identity_payload;
+    if (identity_payload) { V->prov_data = L.kg_data; V->prov_data_ver = L.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = L.kg_bits; V->prov_ks = L.kg_ks; }
     return GS4D_OK;
 }
 
@@ -670,6 +757,11 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     L.depth_sort.hist_bits = span < (1u << 8) ? 8 : span < (1u << 16) ? 16 : span < (1u << 24) ? 24 : 32;
     K->version++; I->version++;
     L.kg_buf = keys; L.kg_ver = K->version; L.kg_n = n;
+    L.kg_idx = idx; L.kg_idx_ver = I->version; L.kg_data = data; L.kg_data_ver = D->version; L.kg_bits = L.depth_sort.hist_bits;
+    L.kg_ks.mode = key_mode == GS4D_KEY_REF_INV_EUCLID ? KEYSRC_REF : KEYSRC_VIEWZ;
+    L.kg_ks.t = t; L.kg_ks.camx = cam[0]; L.kg_ks.camy = cam[1]; L.kg_ks.camz = cam[2];
+    L.kg_ks.vr0 = c->u.view[2]; L.kg_ks.vr1 = c->u.view[6]; L.kg_ks.vr2 = c->u.view[10]; L.kg_ks.vr3 = c->u.view[14];
+    L.kg_ks.bias = bias;
     return GS4D_OK;
 }
 
@@ -684,11 +776,36 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     Lane& L = lane(c);
     a.lane = c->cur; a.fb = c->cur_fb;
     a.fb_was_clear = c->fbs[c->cur_fb].is_clear;
+    // Which path: the unordered one whenever the blend order is known without reading a sort index — instance k draws record k, or the
+    // bound index is this library's sort of its own depth keys for exactly these records — and the lists are short enough to be
+    // ordered in LDS (validated on the device; a draw that turns out otherwise is re-run on the ordered path).
+    a.v2 = false;
+    if (c->atomic_rank && c->path_pref != 1) {
+        Buffer* data = getbuf(c, a.data);
+        bool ok = false;
+        size_t nkeys = 0;
+        if (data && (a.quads || a.mode == GS4D_MODE_4D_DIRECT || a.mode == GS4D_MODE_2D)) {
+            nkeys = std::min(a.instances, data->bytes / (a.quads ? 288 : a.mode == GS4D_MODE_2D ? 48 : 96));
+            a.ks = KeySrc(); a.keybits = 1; while (a.keybits < 32 && ((size_t)1 << a.keybits) < nkeys) ++a.keybits;
+            ok = nkeys > 0;
+        } else if (data && a.mode == GS4D_MODE_4D_SORTED) {
+            const Buffer* ob = getbuf(c, a.order);
+            if (ob && ob->prov_valid && ob->version == ob->prov_ver && a.data == ob->prov_data && data->version == ob->prov_data_ver && a.instances == ob->prov_n && data->bytes / 96 == ob->prov_n) {
+                a.ks = ob->prov_ks; a.keybits = ob->prov_bits; ok = true;
+            }
+        }
+        if (ok && c->long_lists) {
+            // the lists were too long last time: stay on the ordered path, but probe again now and then if they look short on average
+            const uint64_t tiles = (uint64_t)c->tiles_x * c->tiles_y;
+            if (++c->ordered_draws >= 64 && c->stat_entries / (tiles ? tiles : 1) <= V2_MAX_LIST / 8) c->long_lists = false; else ok = false;
+        }
+        a.v2 = ok;
+    }
     const size_t before = L.proj_n;
     L.proj_n = 0;
     rc = run_draw(c, a, true);
     if (rc) { L.proj_n = before; return rc; }
-    if (L.proj_n) { L.pending = true; L.pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; }   // proj_n != 0 <=> raster work was enqueued
+    if (L.proj_n) { L.pending = true; L.pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; if (a.v2) c->stat_v2_draws++; }   // proj_n != 0 <=> raster work was enqueued
     else L.proj_n = before;
     if (c->profiling) { if (c->prof_frame < gs4d_ctx::PROF_FRAMES && c->prof_tick % (uint64_t)c->prof_every == 0) c->prof_frame++; c->prof_tick++; }
     return GS4D_OK;
@@ -896,7 +1013,7 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
     stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = c->stat_reruns; stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
-    stats[4] = c->stat_depth_passes; stats[5] = c->stat_tile_passes; stats[6] = (uint64_t)c->nlanes; stats[7] = 0;
+    stats[4] = c->stat_depth_passes; stats[5] = c->stat_tile_passes; stats[6] = (uint64_t)c->nlanes; stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }
 

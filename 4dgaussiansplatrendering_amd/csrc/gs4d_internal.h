@@ -36,6 +36,7 @@ struct SortScratch {
     uint32_t epoch = 0;                // tag of the look-back words of the latest pass launch
     uint32_t ticket_base = 0;          // value of the ticket counter (totals[64]) at the start of the next pass launch
     bool atomic_rank = false;          // LDS-atomic ranking verified on this device (lds_atomic_order_selftest)
+    int shape_knob = 0, rank_knob = 0; // test / tuning hooks read at context creation: GS4D_SORT_SHAPE (1..6: tile shape of a pass), GS4D_SORT_RANK (1 = ballot ranking, 2 = LDS-atomic ranking)
     uint32_t* totals = nullptr;                                             // [256] spare words (err word when `err` is not set)
     uint32_t* err = nullptr;                                                // not owned: device word raised when a look-back spin times out
 };
@@ -90,13 +91,67 @@ __device__ __forceinline__ void os_hist_flush(uint32_t (*h)[256], uint32_t* __re
 }
 #endif
 
+// ---- the unordered draw path (tilelist.hip, composite2.hip): per-tile lists built with atomics, ordered inside the compositor ----
+// Blend order of the instances = ascending (key, record index).  Where that key comes from:
+//   KEYSRC_INDEX   instance k draws record k (4D-direct, 3D-full, 2D): key = k
+//   KEYSRC_REF / KEYSRC_VIEWZ   the bound sort index is the library's own stable sort of the keys gs4d_keygen produced for exactly
+//                  these records (tracked by buffer versions): "instance order" == ascending (depth key, record index), so the key
+//                  is recomputed per record with k_keygen's arithmetic and the sort index is never read.
+enum { KEYSRC_INDEX = 0, KEYSRC_REF = 1, KEYSRC_VIEWZ = 2 };
+struct KeySrc {
+    int mode = KEYSRC_INDEX;
+    float t = 0, camx = 0, camy = 0, camz = 0;
+    float vr0 = 0, vr1 = 0, vr2 = 0, vr3 = 0;   // view row 2 at keygen time (KEYSRC_VIEWZ)
+    uint32_t bias = 0;                           // subtracted from the key's bit pattern (host-proven lower bound, as in the depth sort)
+};
+struct TileCount {                               // tcount == nullptr: the ordered path (no counting in the projection kernel)
+    uint32_t* tcount = nullptr;                  // [tiles] entries per tile; all-zero between draws (k_tilescan clears what it reads)
+    uint32_t* skey = nullptr;                    // [records] blend-order key of every record
+    int tiles_x = 0, shard_rank = 0, shard_world = 1;
+    KeySrc ks;
+};
+constexpr uint32_t V2_MAX_LIST = 2048;           // longest per-tile list the compositor sorts in LDS; beyond it a draw uses the ordered path
+struct TileLists {
+    uint32_t* tcount = nullptr; uint32_t* tstart = nullptr; uint32_t* cursor = nullptr; size_t tiles_cap = 0;   // one allocation
+    uint32_t* skey = nullptr; size_t skey_cap = 0;
+};
+hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_t nrecords);
+void tile_lists_free(TileLists& t);
+// total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list;
+// total_host (pinned, mapped) receives [0..3] and the longest list at [5]
+hipError_t launch_tilescan(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, size_t cap, uint32_t hint);
+hipError_t launch_tile_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* entries, int tiles_x, int shard_rank, int shard_world);
+hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
+                               int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits);
+
+#ifdef __HIPCC__
+// tiles touched by a pixel rectangle (x0|y0<<16, x1|y1<<16; x0 > x1: none), restricted to the tile rows ty % world == rank
+struct TRect { uint32_t tx0, ty0, wx, rows, tstep, count; };
+__device__ __forceinline__ TRect tile_rect(uint32_t rect0, uint32_t rect1, uint32_t shard_rank, uint32_t shard_world) {
+    TRect r{ 0u, 0u, 0u, 0u, 1u, 0u };
+    const uint32_t x0 = rect0 & 0xFFFFu, y0 = rect0 >> 16, x1 = rect1 & 0xFFFFu, y1 = rect1 >> 16;
+    if (x0 > x1 || y0 > y1) return r;
+    r.tx0 = x0 / TILE; r.ty0 = y0 / TILE; r.wx = x1 / TILE - r.tx0 + 1u;
+    const uint32_t ty1 = y1 / TILE;
+    r.rows = ty1 - r.ty0 + 1u;
+    if (shard_world > 1u) {
+        const uint32_t first = r.ty0 + (shard_rank + shard_world - r.ty0 % shard_world) % shard_world;
+        r.rows = first > ty1 ? 0u : (ty1 - first) / shard_world + 1u;
+        r.ty0 = first; r.tstep = shard_world;
+    }
+    r.count = r.wx * r.rows;
+    return r;
+}
+__device__ __forceinline__ uint32_t tile_of(const TRect& r, uint32_t j, uint32_t tiles_x) { return (r.ty0 + (j / r.wx) * r.tstep) * tiles_x + r.tx0 + j % r.wx; }
+#endif
+
 // ---- preprocess.hip ----
 hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* 6 planes of n float4 */, uint32_t* bbox /* [16], preset: min = ~0, max = 0 */);
 // Each preprocess launch also writes the compact pixel rectangle of every record.
 struct PreOut { float4* proj; uint2* rects; };
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& u, int W, int H, PreOut out);
-hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, PreOut out);
-hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, PreOut out);
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
+hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
+hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 
 // ---- binning.hip ----
 struct BinScratch {

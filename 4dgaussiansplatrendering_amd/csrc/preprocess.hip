@@ -108,8 +108,8 @@ __device__ __forceinline__ void eigen2(float u00, float u01, float u10, float u1
 __device__ __forceinline__ bool fin(float x) { return isfinite(x); }
 
 // Window-space set-up + record store.  ncx,ncy = NDC centre; kx,ky = NDC scale of the quad offset.
-__device__ __forceinline__ void emit(const PreOut& out, uint32_t i, bool valid, const Quad& q, float ncx, float ncy, float kx, float ky,
-                                     int W, int H, float r, float g, float b, float alpha) {
+__device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid, const Quad& q, float ncx, float ncy, float kx, float ky,
+                                      int W, int H, float r, float g, float b, float alpha) {
     float cx = 0, cy = 0, a0x = 0, a0y = 0, a1x = 0, a1y = 0, hx = 0, hy = 0;
     uint32_t rect0 = 1u, rect1 = 0u;           // empty
     if (valid) {
@@ -144,6 +144,47 @@ __device__ __forceinline__ void emit(const PreOut& out, uint32_t i, bool valid, 
     o[1] = make_float4(a1x, a1y, alpha, r);
     o[2] = make_float4(g, b, __uint_as_float(rect0), __uint_as_float(rect1));
     o[3] = make_float4(hx, hy, valid ? 1.0f : 0.0f, 0.0f);
+    return make_uint2(rect0, rect1);
+}
+
+// Unordered draw path: the projection kernel also counts, per 8x8 tile, the entries its records will put on the tile lists (plain
+// no-return atomics, nothing waits for them) and stores each record's blend-order key.  Called by every lane of the wave that is still
+// alive (lanes past the end have returned): footprints of more than 16 tiles are counted by the whole wave.
+__device__ __forceinline__ void count_tiles(const TileCount& tc, uint32_t i, uint2 rect, uint32_t key) {
+    tc.skey[i] = key;
+    const TRect r = tile_rect(rect.x, rect.y, (uint32_t)tc.shard_rank, (uint32_t)tc.shard_world);
+    const bool big = r.count > 16u;
+    if (!big) for (uint32_t j = 0; j < r.count; ++j) atomicAdd(&tc.tcount[tile_of(r, j, (uint32_t)tc.tiles_x)], 1u);
+    uint64_t m = __ballot(big);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        TRect rr;
+        rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
+        rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
+        for (uint32_t j = lane; j < rr.count; j += 64u) atomicAdd(&tc.tcount[tile_of(rr, j, (uint32_t)tc.tiles_x)], 1u);
+    }
+}
+
+// the depth key k_keygen (sort.hip) writes for this record, as a bit pattern relative to the host-proven lower bound
+__device__ __forceinline__ uint32_t blend_key_4d(const KeySrc& ks, uint32_t i, const float4& p, const float4& s) {
+    if (ks.mode == KEYSRC_INDEX) return i;
+    float key;
+    if (ks.mode == KEYSRC_REF) {
+        float ct = ks.t - p.w;                             // Scenes.h:30
+        float x = p.x + s.x * ct;                          // :31-33
+        float y = p.y + s.y * ct;
+        float z = p.z + s.z * ct;
+        float dx = x - ks.camx, dy = y - ks.camy, dz = z - ks.camz;     // :317
+        key = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);                // :318
+    } else {
+        float k = (1.0f / s.w) * (ks.t - p.w);
+        float x = p.x + k * s.x, y = p.y + k * s.y, z = p.z + k * s.z;
+        float zv = ((ks.vr0 * x + ks.vr1 * y) + ks.vr2 * z) + ks.vr3;
+        key = 1.0f / fmaxf(-zv, 1e-20f);
+    }
+    return __float_as_uint(key) - ks.bias;
 }
 
 // …Instanced.GLSL:97-147 == Splat3DVertexShaderFull.GLSL:45-95.  C[c][r] = 3x3 covariance.
@@ -194,7 +235,7 @@ __device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict__ soa, uint32_t n, PU u, PreOut out) {
+__global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict__ soa, uint32_t n, PU u, PreOut out, TileCount tc) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float4 pos = soa[i], col = soa[(size_t)n + i];
@@ -216,10 +257,11 @@ __global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict_
         for (int r = 0; r < 3; ++r) C[c][r] = S[c][r] - a[r] * tv[c];              // :89-95
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, mx, my, mz, C, q, ncx, ncy);
-    emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w);
+    const uint2 rect = emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w);
+    if (tc.tcount) count_tiles(tc, i, rect, blend_key_4d(tc.ks, i, pos, s3));
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__ verts, uint32_t n, PU u, PreOut out) {
+__global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__ verts, uint32_t n, PU u, PreOut out, TileCount tc) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float* v = verts + (size_t)72 * i;      // vertex 0 of the quad: {vpos2, spos3, col4, sig9}
@@ -230,10 +272,11 @@ __global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__
         for (int r = 0; r < 3; ++r) C[c][r] = v[9 + 3 * c + r];
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, v[2], v[3], v[4], C, q, ncx, ncy);
-    emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8]);
+    const uint2 rect = emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8]);
+    if (tc.tcount) count_tiles(tc, i, rect, i);
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__ recs, uint32_t n, PU u, PreOut out) {
+__global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__ recs, uint32_t n, PU u, PreOut out, TileCount tc) {
     uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     const float* rec = recs + (size_t)12 * i;
@@ -254,7 +297,8 @@ __global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__
     float clipz = P[10] * zc + P[14] * wc4;
     bool valid = (clipw > 0.0f) && !(clipz < -clipw || clipz > clipw);
     float kx = P[0] / clipw, ky = P[5] / clipw;
-    emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
+    const uint2 rect = emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
+    if (tc.tcount) count_tiles(tc, i, rect, i);
 }
 
 static PU make_pu(const Uniforms& un, int W, int H) {
@@ -264,19 +308,19 @@ static PU make_pu(const Uniforms& un, int W, int H) {
     return u;
 }
 
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, PreOut out) {
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
     if (n == 0) return hipSuccess;
-    k_preprocess_4d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(soa, (uint32_t)n, make_pu(un, W, H), out);
+    k_preprocess_4d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(soa, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, PreOut out) {
+hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
     if (n == 0) return hipSuccess;
-    k_preprocess_3d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(verts72, (uint32_t)n, make_pu(un, W, H), out);
+    k_preprocess_3d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(verts72, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, PreOut out) {
+hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
     if (n == 0) return hipSuccess;
-    k_preprocess_2d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(rec48, (uint32_t)n, make_pu(un, W, H), out);
+    k_preprocess_2d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(rec48, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }
 

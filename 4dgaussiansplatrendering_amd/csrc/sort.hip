@@ -93,6 +93,13 @@ hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, 
 // the dispatch order.  Every spin is bounded as well: on time-out the kernel raises `err` and leaves, and the host reports the
 // frame as failed instead of hanging the GPU or returning wrong data.
 // ------------------------------------------------------------------------------------------------
+// Per-tile wall-clock stamps of one pass (tools/stamps.py) exist only in tuning builds (make TUNING=1): release kernels carry no
+// ablation branches.
+#ifdef GS4D_TUNING
+#define OS_STAMP(k) do { if (stamps && tid == 0) stamps[tile * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define OS_STAMP(k) do { } while (0)
+#endif
 constexpr uint32_t OS_GROUP = 32;         // tiles per look-back group
 constexpr uint32_t OS_SUPER = 32;         // groups per super-group
 typedef unsigned long long u64;
@@ -133,13 +140,15 @@ __global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ ke
 // Which passes are live, and which buffers pass `p` reads and writes.  Returns false when pass p is skipped.
 // A single live pass would end in a scratch buffer: one identity pass is then run as well (a stable copy), so the number of
 // executed passes is 0, 2, 3 or 4 and the result always lands in buffer 0.
-__device__ __forceinline__ bool os_schedule(uint32_t* s_live /* [4] 0/1, may be amended */, int passes, int p, int& src, int& dst) {
-    int k = 0;
-    for (int q = 0; q < passes; ++q) k += s_live[q] ? 1 : 0;
-    if (k == 1) { for (int q = 0; q < passes; ++q) if (!s_live[q]) { s_live[q] = 1u; ++k; break; } }   // every thread writes the same value
-    int j = 0;
-    for (int q = 0; q < p; ++q) j += s_live[q] ? 1 : 0;
-    if (!s_live[p]) return false;
+// `live` is a register copy of the workgroup's live mask (bit q: pass q moves keys): every thread derives the same schedule from
+// the same word — nothing is amended in shared memory, so waves cannot disagree about it.
+__device__ __forceinline__ bool os_schedule(uint32_t live, int passes, int p, int& src, int& dst) {
+    const uint32_t all = (1u << passes) - 1u;
+    live &= all;
+    int k = __popc(live);
+    if (k == 1) { const uint32_t deadm = all & ~live; live |= deadm & (0u - deadm); ++k; }      // revive the first dead pass (passes >= 2)
+    if (!((live >> p) & 1u)) return false;
+    const int j = __popc(live & ((1u << p) - 1u));
     // buffer after i executed passes: even k: 0,1,0,1,...   odd k (>= 3): 0,1,2,0,1,0,...
     auto buf_at = [k](int i) { if (k & 1) { if (i <= 2) return i; return (i - 3) & 1; } return i & 1; };
     src = buf_at(j);
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     __shared__ uint32_t loff[256];      // first local slot of digit d in the reordered tile
     __shared__ uint32_t gpos[256];      // global slot of that first element
     __shared__ uint32_t s_tmp[4];
-    __shared__ uint32_t s_live[OS_MAX_PASSES];
+    __shared__ uint32_t s_dead;          // bit q: one digit of pass q holds every key (the pass is a stable identity)
     __shared__ uint32_t s_tile;
 
     const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     // workgroups are dispatched per XCD, so each kernel's late tiles can fill the XCD the other kernel's early tiles need.)
     // The ticket's round trip overlaps the histogram loads below, which do not depend on the tile.
     if (tid == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
-    if (tid < OS_MAX_PASSES) s_live[tid] = 1u;
+    if (tid == 1u) s_dead = 0u;
     for (uint32_t q = tid; q < WAVES * 256u; q += THREADS) (&wcnt[0][0])[q] = 0u;
     uint32_t tot = 0, dead = 0;
     if (tid < 256u) {
@@ -312,18 +321,18 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         }
     }
     __syncthreads();
+    if (dead) atomicOr(&s_dead, dead);                            // at most one thread per dead pass
     const uint32_t tile = s_tile;
     const uint32_t ntiles = (n + TILE_KEYS - 1u) / TILE_KEYS;
     // housekeeping for the NEXT launch of this sorter: its group accumulators (every workgroup a slice), its histogram slot
     for (uint32_t q = tile * THREADS + tid; q < acc_words; q += gridDim.x * THREADS) acc_next[q] = 0ull;
     if (pass == 0 && tile == 0) { for (uint32_t q = tid; q < OS_SLOT_WORDS; q += THREADS) ghist_other[q] = 0u; }
-    if (tile >= ntiles) return;                                   // uniform
-    if (stamps && tid == 0) stamps[tile * 8 + 0] = wall_clock64();
-    const int shift = 8 * pass;
-    for (int q = 0; q < passes; ++q) if ((dead >> q) & 1u) s_live[q] = 0u;
     __syncthreads();
+    if (tile >= ntiles) return;                                   // uniform
+    OS_STAMP(0);
+    const int shift = 8 * pass;
     int src, dst;
-    if (!os_schedule(s_live, passes, pass, src, dst)) return;    // uniform: this pass is an identity
+    if (!os_schedule(~s_dead, passes, pass, src, dst)) return;   // uniform: this pass is an identity
     const uint32_t* __restrict__ keys_in = bufs.k[src]; const uint32_t* __restrict__ vals_in = bufs.v[src];
     uint32_t* __restrict__ keys_out = bufs.k[dst]; uint32_t* __restrict__ vals_out = bufs.v[dst];
 
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         val[j] = valid ? vals_in[i] : 0u;
     }
     const uint32_t digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid);     // overlaps the loads above
-    if (stamps && tid == 0) stamps[tile * 8 + 1] = wall_clock64();
+    OS_STAMP(1);
 
     if (ATOMIC_RANK) {
         // rank = value returned by an LDS atomic add on the wave's digit counter.  Stable only because the LDS unit serialises the
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         if (grp + 1u < ngroups) (void)__hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1ull << 32) | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (sup + 1u < nsuper) (void)__hip_atomic_fetch_add(acc + (size_t)(acc_groups + sup) * 256u + tid, (1ull << 32) | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (stamps && tid == 0) stamps[tile * 8 + 2] = wall_clock64();
+    OS_STAMP(2);
     // local run starts, then the reorder inside LDS — none of it needs the other tiles, so it overlaps their publishing
     const uint32_t lo_ = digit_excl_scan<THREADS>(cnt, s_tmp, tid);
     if (tid < 256u) loff[tid] = lo_;
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
             svals[l] = val[j];
         }
     }
-    if (stamps && tid == 0) stamps[tile * 8 + 3] = wall_clock64();
+    OS_STAMP(3);
     // look back, one memory round trip: the tiles of this group before this one (their words), the groups of this super-group
     // before this group and the super-groups before this one (their accumulators, complete when every member has arrived)
     if (tid < 256u) {
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         gpos[tid] = digit_base + prefix;
     }
     __syncthreads();
-    if (stamps && tid == 0) stamps[tile * 8 + 4] = wall_clock64();
+    OS_STAMP(4);
     const uint32_t tcount = min(TILE_KEYS, n - tbase);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
             __builtin_nontemporal_store(svals[l], vals_out + o);
         }
     }
-    if (stamps && tid == 0) stamps[tile * 8 + 5] = wall_clock64();
+    OS_STAMP(5);
 }
 
 // Does an LDS atomic add executed by a whole wave return, to the lanes that hit the same address, their rank in ascending lane order?
@@ -534,8 +543,12 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     }
     s.hist_pending = false;
     s.flip ^= 1;
+#ifdef GS4D_TUNING
     static const char* stampf = getenv("GS4D_SORT_STAMP_FILE");
     static const int stamp_pass = getenv("GS4D_SORT_STAMP_PASS") ? atoi(getenv("GS4D_SORT_STAMP_PASS")) : 0;
+#else
+    const char* stampf = nullptr; const int stamp_pass = 0;
+#endif
     u64* stamps = nullptr;
     if (stampf && hipMalloc(&stamps, (size_t)tiles * 64) != hipSuccess) stamps = nullptr;
     uint32_t* status = s.hist + 2 * OS_SLOT_WORDS;
@@ -577,10 +590,8 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
     if (e != hipSuccess) return e;
     int passes = (key_bits + 7) / 8;
     if (passes < 2) passes = 2;                       // an even number of executed passes always exists (see os_schedule)
-    static const int knob = getenv("GS4D_SORT_SHAPE") ? atoi(getenv("GS4D_SORT_SHAPE")) : 0;      // tuning knob (experiments only)
-    const int shape = knob ? knob : (n <= ((size_t)3 << 20) ? 2 : 5);     // 4096-key tiles for small sorts, 8192-key tiles beyond
-    static const int rank_knob = getenv("GS4D_SORT_RANK") ? atoi(getenv("GS4D_SORT_RANK")) : 0;   // tuning knob: 1 = ballot ranking, 2 = LDS-atomic ranking
-    const bool atomic_rank = rank_knob ? rank_knob == 2 : s.atomic_rank;
+    const int shape = s.shape_knob ? s.shape_knob : (n <= ((size_t)3 << 20) ? 2 : 5);     // 4096-key tiles for small sorts, 8192-key tiles beyond
+    const bool atomic_rank = s.rank_knob ? s.rank_knob == 2 : s.atomic_rank;
 #define GS4D_OS(T, I) (atomic_rank ? onesweep<T, I, true>(st, s, keys, vals, n, n_dev, passes, have_hist) : onesweep<T, I, false>(st, s, keys, vals, n, n_dev, passes, have_hist))
     switch (shape) {
     case 1: return GS4D_OS(256, 8);

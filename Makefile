@@ -7,10 +7,14 @@ ARCH  ?= gfx950
 LIB   := $(PKG)/libgs4d.so
 
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function
+# make TUNING=1: ablation knobs and per-tile stamps compiled into the kernels (experiments only; never the shipped build)
+ifdef TUNING
+HIPFLAGS += -DGS4D_TUNING
+endif
 # keygen/sort and preprocess must round exactly like the CPU expressions they are checked against
 STRICT   := -ffp-contract=off
 
-OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(HOST)/gs4d_host.o
+OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(CSRC)/tilelist.o $(CSRC)/composite2.o $(HOST)/gs4d_host.o
 
 .PHONY: all lib oracle ref clean demo
 all: lib oracle demo
@@ -24,7 +28,7 @@ $(CSRC)/sort.o: $(CSRC)/sort.hip $(CSRC)/gs4d_internal.h include/gs4d.h
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
 $(CSRC)/preprocess.o: $(CSRC)/preprocess.hip $(CSRC)/gs4d_internal.h include/gs4d.h
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/gs4d_internal.h include/gs4d.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/gs4d_internal.h $(CSRC)/composite_common.h include/gs4d.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(HOST)/gs4d_host.o: $(HOST)/gs4d_host.cpp include/gs4d.h
 	$(HIPCC) -O2 -std=c++17 -fPIC -fvisibility=hidden $(STRICT) -x c++ -c $< -o $@

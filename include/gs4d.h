@@ -78,6 +78,12 @@ GS4D_API int gs4d_buffer_subdata(gs4d_ctx* ctx, gs4d_buf buf, size_t offset, con
 GS4D_API int gs4d_buffer_read(gs4d_ctx* ctx, gs4d_buf buf, size_t offset, void* out, size_t bytes);  /* blocking; no reference counterpart (tests/tools) */
 GS4D_API int gs4d_buffer_destroy(gs4d_ctx* ctx, gs4d_buf buf);
 GS4D_API int gs4d_buffer_device_ptr(gs4d_ctx* ctx, gs4d_buf buf, void** dptr, size_t* bytes);        /* zero-copy interop with a caller that owns HIP memory */
+/* The caller is about to overwrite `buf` through that pointer with work on its own stream (gs4d_set_stream).  Call this BEFORE queueing
+ * the write, every time: (a) the caller's stream is made to wait for every kernel the library has queued that still uses the buffer
+ * (without a caller stream the call blocks until they have finished), (b) the contents count as changed from here on — the library keeps
+ * derived data per buffer version (a repacked copy of the records, bounds of the sort keys, what a sorted index was sorted by) and
+ * otherwise goes on using it.  The library's next call that uses the buffer is ordered after the caller's stream as gs4d_set_stream says. */
+GS4D_API int gs4d_buffer_invalidate(gs4d_ctx* ctx, gs4d_buf buf);
 /* glBindBufferBase(GL_SHADER_STORAGE_BUFFER, slot, buf) (Scenes.h:336, ShareStorageBuffer.cpp:20-23); slots 0..7 */
 GS4D_API int gs4d_bind_storage(gs4d_ctx* ctx, int slot, gs4d_buf buf);
 
@@ -117,7 +123,7 @@ GS4D_API int gs4d_read_pixels_rgba8_device(gs4d_ctx* ctx, void* dptr, size_t byt
 GS4D_API int gs4d_read_frame_rgba8_device(gs4d_ctx* ctx, int frames_back, void* dptr, size_t bytes);
 /* Name the caller's HIP stream (hipStream_t passed as void*; NULL: none).  The library keeps running on its own streams, but from now
  * on (a) whatever the caller queued on that stream before an enqueueing call (keygen, sort, draw, device read-back) happens before the
- * work of that call — e.g. a kernel of the caller's that fills a buffer obtained with gs4d_buffer_device_ptr — and (b) whatever the
+ * work of that call — e.g. a kernel of the caller's that fills a buffer obtained with gs4d_buffer_device_ptr (see gs4d_buffer_invalidate) — and (b) whatever the
  * caller queues on it after a device read-back sees the pixels — e.g. an RCCL gather of the frames.  No host synchronisation. */
 GS4D_API int gs4d_set_stream(gs4d_ctx* ctx, void* hip_stream);
 /* Single-frame sharding over several GPUs (secondary mode; config 5): rows of 8x8-pixel tiles are dealt round-robin,
@@ -138,7 +144,8 @@ GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);           
  * ms[frame][stage][2].  Shows how consecutive frames overlap.  Blocking; does not restart the ring (gs4d_get_timings does). */
 GS4D_API int gs4d_get_timeline(gs4d_ctx* ctx, float* ms, int max_frames, int* frames);
 GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[8]);                    /* [0] tile-list entries of the last draw, [1] capacity, [2] re-runs after overflow, [3] tiles,
-                                                                                      [4] radix passes launched by the last gs4d_sort_pairs, [5] by the last draw's tile sort, [6] frame lanes, [7] 0 */
+                                                                                      [4] radix passes launched by the last gs4d_sort_pairs, [5] by the last draw's tile sort (0: the draw built unordered tile lists),
+                                                                                      [6] frame lanes, [7] low 32 bits: draws so far on the unordered tile-list path, high 32 bits: longest tile list of the last such draw */
 /* Projected records of the last draw, 16 floats per record in record order:
  * cx, cy, a0x, a0y, a1x, a1y, alpha, r, g, b, tile-rect (2 words, bit patterns), hx, hy, valid(1/0), 0 */
 GS4D_API int gs4d_debug_read_projected(gs4d_ctx* ctx, float* out16, size_t nrecords);

@@ -243,6 +243,21 @@ GS4DO_API void gs4do_keygen(const float* records, size_t n, float t, const float
     }
 }
 
+// GS4D_KEY_VIEW_Z — the build's own extra key mode (the north star's "view-space depth keying"; the reference has no such key):
+// key = 1 / max(-z_view, 1e-20) of the shader's time-conditioned mean  mu + (t - mu_t)/Sigma44 * Sigma[3].xyz
+// (Splat4DVertexShaderInstanced.GLSL:86), z_view = row 2 of uView applied to it, summed left to right.  Nearer => larger key,
+// so ascending order is far -> near like the reference key.  Restated here only so that the GPU mode has a checker.
+GS4DO_API void gs4do_keygen_viewz(const float* records, size_t n, float t, const float V[16], uint32_t* idx_out, float* key_out) {
+    for (size_t i = 0; i < n; ++i) {
+        const float* rec = records + 24 * i;
+        float k = (1.0f / rec[8 + 15]) * (t - rec[3]);
+        float x = rec[0] + k * rec[8 + 12 + 0], y = rec[1] + k * rec[8 + 12 + 1], z = rec[2] + k * rec[8 + 12 + 2];
+        float zv = ((V[2] * x + V[6] * y) + V[10] * z) + V[14];
+        idx_out[i] = (uint32_t)i;
+        key_out[i] = 1.0f / fmaxf(-zv, 1e-20f);
+    }
+}
+
 // Sort contract: stable ascending by the uint32 bit pattern of the key, payload follows.
 // This is the CPU "port" used as the checker and as the cpu_baseline sort stage: 4-pass 8-bit LSD.
 GS4DO_API void gs4do_sort_pairs(uint32_t* keys, uint32_t* vals, size_t n) {

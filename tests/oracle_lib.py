@@ -109,6 +109,16 @@ def keygen(records, t, cam):
     return idx, key
 
 
+def keygen_viewz(records, t, view):
+    """The build's extra key mode GS4D_KEY_VIEW_Z (no reference counterpart): 1 / view-space depth of the conditioned mean."""
+    rec = _f32(records).reshape(-1, 24)
+    n = rec.shape[0]
+    idx = np.zeros(n, np.uint32)
+    key = np.zeros(n, np.float32)
+    lib().gs4do_keygen_viewz(_p(rec), C.c_size_t(n), C.c_float(t), _p(_f32(view)), _p(idx), _p(key))
+    return idx, key
+
+
 def sort_pairs(keys_u32, vals_u32, which="lsd"):
     k = np.array(keys_u32, dtype=np.uint32, copy=True)
     v = np.array(vals_u32, dtype=np.uint32, copy=True)

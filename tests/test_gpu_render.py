@@ -14,6 +14,17 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["auto", "ordered"])
+def draw_path(request, monkeypatch):
+    """Every test of this module runs twice: with the library choosing how a draw builds its tile lists (unordered lists ordered in
+    the compositor wherever the blend order is known without reading the sort index) and with instance-ordered lists forced."""
+    if request.param == "ordered":
+        monkeypatch.setenv("GS4D_DRAW_PATH", "ordered")
+    else:
+        monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    return request.param
+
+
 def cam_mats(gs4d, cam, W, H):
     view = gs4d.look_at(cam[0], cam[1])
     proj = gs4d.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
@@ -71,8 +82,8 @@ def linf(a, b):
     return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))))
 
 
-@pytest.fixture(scope="module")
-def ctx1080(gs4d):
+@pytest.fixture
+def ctx1080(gs4d, draw_path):
     c = gs4d.Context(1920, 1080)
     yield c
     c.close()
