@@ -54,6 +54,12 @@ def _load():
         "gs4d_keygen": (i32, [vp, u32, f32, vp, u32, u32, sz, i32]),
         "gs4d_draw_instanced": (i32, [vp, sz]),
         "gs4d_draw_quads": (i32, [vp, u32, sz]),
+        "gs4d_draw_lines": (i32, [vp, vp, sz, i32, i32, vp, vp, f32]),
+        "gs4d_host_camera_input": (None, [vp, vp, vp, vp]),
+        "gs4d_host_camera_rotate": (None, [vp, C.c_double, C.c_double]),
+        "gs4d_host_camera_look_at_point": (None, [vp, vp]),
+        "gs4d_host_camera_viewport": (None, [i32, i32, vp]),
+        "gs4d_host_camera_focal": (None, [f32, i32, i32, vp]),
         "gs4d_read_pixels": (i32, [vp, vp, sz]),
         "gs4d_read_pixels_device": (i32, [vp, vp, sz]),
         "gs4d_read_pixels_rgba8_device": (i32, [vp, vp, sz]),
@@ -362,6 +368,13 @@ class Context:
 
     def draw_quads(self, vertices, nquads):
         self._chk(_lib.gs4d_draw_quads(self._h, vertices, nquads))
+
+    def draw_lines(self, verts, rgba, width=1.0, viewproj=None, strip=False):
+        """Renderer::DrawLine/DrawGrid/DrawAxis: verts (n, 3) with viewproj, or (n, 2) NDC positions; GL_LINES pairs or a GL_LINE_STRIP."""
+        v = _f32(verts)
+        dims = v.shape[-1]
+        vp = _f32(viewproj) if viewproj is not None else None
+        self._chk(_lib.gs4d_draw_lines(self._h, _ptr(v), v.size // dims, dims, 1 if strip else 0, _ptr(vp) if vp is not None else None, _ptr(_f32(rgba)), width))
 
     def read_pixels(self):
         out = np.empty((self.height, self.width, 4), np.float32)

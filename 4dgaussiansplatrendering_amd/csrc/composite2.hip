@@ -4,7 +4,7 @@
 // Shader/Splats4D/Splat4DFragShader.GLSL:16-31 and the 3D/2D variants, blend Application.cpp:150-154): the chunk walk is the shared
 // composite_chunk().  What differs is where the blend order comes from.  tilelist.hip leaves every tile an UNORDERED list of
 // (key, record) entries; "instance order" — the order the reference's ROP blends in — is ascending (key, record) (KeySrc,
-// gs4d_internal.h).  The wave reads its whole list into registers (PER entries per lane; k_tilescan guarantees it fits, otherwise the
+// gs4d_internal.h).  The wave reads its whole list into registers (PER entries per lane; k_bucket_tiles guarantees it fits, otherwise the
 // draw was aborted and re-run on the ordered path), sorts it with a wave-local LSD radix sort over 6-bit digits — 64 counters, one
 // per lane — and then walks it from the end (front-most) as composite.hip does.
 //
@@ -59,7 +59,7 @@ struct WaveSort {
 };
 
 template <bool PREMULT_C, int PER>
-__global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart,
+__global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
                                                      const uint32_t* __restrict__ total, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
                                                      float4* __restrict__ fb, int key_passes, int rec_passes) {
     __shared__ float4 stage[64 * 3];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const uint32_t start = tstart[tile];
-    const uint32_t E = min(tstart[tile + 1] - start, (uint32_t)(64 * PER));      // k_tilescan guarantees the bound; min() keeps a broken promise inside LDS
+    const uint32_t E = min(tcnt[tile], (uint32_t)(64 * PER));                    // k_bucket_tiles guarantees the bound; min() keeps a broken promise inside LDS
 
     if (E > 1u) {
         WaveSort<PER> ws;
@@ -120,9 +120,9 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
 }
 
 template <bool PREMULT_C>
-static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* total, int tiles_x, int W, int H,
+static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int W, int H,
                             int fb_is_clear, float4 c, float4* fb, int kp, int rp) {
-#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp)
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp)
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
@@ -135,15 +135,15 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
     return hipGetLastError();
 }
 
-hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
+hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits) {
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
     int per = 1; while ((uint32_t)per * 64u < hint) per *= 2;
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid((unsigned)(tiles_x * tiles_y));
     const int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
-    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp)
-                     : launch_v2<false>(st, per, grid, proj, entries, tstart, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp);
+    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp)
+                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp);
 }
 
 } // namespace gs4d

@@ -66,6 +66,7 @@ struct DrawArgs {
 
 struct Framebuffer {
     float4* mem = nullptr;
+    uint32_t* linecnt = nullptr;   // per-pixel fragment counters of the overlay-line kernels (lines.hip), allocated on first use, all-zero between calls
     bool is_clear = true;          // content == clear colour, not yet materialised
     int last_lane = -1;            // lane that touched it last
 };
@@ -81,6 +82,7 @@ struct Lane {
     uint32_t* order_copy = nullptr; size_t order_cap = 0;   // private copy of the last draw's sort index (for a re-run after overflow)
     SortScratch depth_sort, pair_sort;
     BinScratch bin;
+    float* line_verts = nullptr; size_t line_cap = 0;   // device copy of the vertices of the latest gs4d_draw_lines (the lane's stream orders its reuse)
     uint32_t* host_total = nullptr;     // pinned + mapped: [0..3] the binning total of the last draw, [4] the error word kernels raise
     uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
     gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
@@ -218,7 +220,7 @@ int ensure_pairs(gs4d_ctx* c, Lane& L, size_t cap) {
     HIPCHK(c, hipStreamSynchronize(L.s));
     if (L.pair_keys) (void)hipFree(L.pair_keys);
     L.pair_keys = L.pair_vals = nullptr; L.pair_cap = 0;
-    HIPCHK(c, hipMalloc(&L.pair_keys, cap * 8));
+    HIPCHK(c, hipMalloc(&L.pair_keys, cap * 16));      // ordered path: tile ids | records (4 + 4 bytes per slot); unordered path: two arrays of (key, record)
     L.pair_vals = L.pair_keys + cap;
     L.pair_cap = cap;
     return GS4D_OK;
@@ -296,17 +298,20 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, 
 // Unordered path: the projection kernel has counted the entries per tile; scan, scatter, composite (tilelist.hip, composite2.hip).
 int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, size_t nrecords, int premult_c) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
+    uint2* tmp = (uint2*)L.pair_keys;              // the lane's entry storage holds 16 bytes per slot: [0, cap) bucket order, [cap, 2 cap) tile order
+    uint2* entries = tmp + L.pair_cap;
     {
         StageTimer t(c, GS4D_T_BINNING);
-        HIPCHK(c, launch_tilescan(L.s, L.tl, ntiles, L.bin.total, L.host_total_dev, L.pair_cap, c->list_hint));
-        HIPCHK(c, hipEventRecord(L.ev_emit, L.s));     // totals, flags and the longest list are in pinned host memory behind this event
-        HIPCHK(c, launch_tile_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, (uint2*)L.pair_keys, c->tiles_x, c->shard_rank, c->shard_world));
+        HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
+        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, tmp, c->tiles_x, c->shard_rank, c->shard_world));
+        HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, L.host_total_dev, tmp, entries, c->list_hint));
     }
+    HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event
     c->stat_tile_passes = 0;
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
         int recbits = 1; while (recbits < 32 && ((size_t)1 << recbits) < nrecords) ++recbits;
-        HIPCHK(c, launch_composite_v2(L.s, L.proj, (const uint2*)L.pair_keys, L.tl.tstart, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, c->clear, F.mem,
+        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, c->clear, F.mem,
                                       c->list_hint, a.keybits, recbits));
     }
     return GS4D_OK;
@@ -336,7 +341,8 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
-    if (a.v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
+    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre);
+    if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
     uint32_t* order_copy = nullptr;
     if (order) {
         if (L.order_cap < a.instances) {
@@ -360,12 +366,12 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
         }
         if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
         { int rc = lane_access(c, *data, false); if (rc) return rc; data->rd_mask |= 1u << a.lane; }
-        if (ob && !a.v2) { int rc = lane_access(c, *ob, false); if (rc) return rc; ob->rd_mask |= 1u << a.lane; }
+        if (ob && !v2) { int rc = lane_access(c, *ob, false); if (rc) return rc; ob->rd_mask |= 1u << a.lane; }
         {
             StageTimer t(c, GS4D_T_PREPROCESS);
             const PreOut po = { L.proj, L.rects };
             TileCount tc;
-            if (a.v2) { tc.tcount = L.tl.tcount; tc.skey = L.tl.skey; tc.tiles_x = c->tiles_x; tc.shard_rank = c->shard_rank; tc.shard_world = c->shard_world; tc.ks = a.ks; }
+            if (v2) { tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.tiles_x = c->tiles_x; tc.shard_rank = c->shard_rank; tc.shard_world = c->shard_world; tc.ks = a.ks; }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, npre, a.u, c->W, c->H, po, tc));
@@ -376,7 +382,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
     if (L.pair_cap < want) { int rc = ensure_pairs(c, L, want); if (rc) return rc; }
-    if (a.v2) return enqueue_raster_v2(c, L, F, a, npre, premult);
+    if (v2) return enqueue_raster_v2(c, L, F, a, npre, premult);
     return enqueue_raster(c, L, F, order, order_copy, a.instances, npre, premult, a.fb_was_clear);
 }
 
@@ -442,6 +448,7 @@ int alloc_fbs(gs4d_ctx* c, int w, int h) {
     { int rc = sync_all(c); if (rc) return rc; }
     for (int i = 0; i < c->nlanes; ++i) {
         if (c->fbs[i].mem) { (void)hipFree(c->fbs[i].mem); c->fbs[i].mem = nullptr; }
+        if (c->fbs[i].linecnt) { (void)hipFree(c->fbs[i].linecnt); c->fbs[i].linecnt = nullptr; }
         HIPCHK(c, hipMalloc(&c->fbs[i].mem, (size_t)w * h * 16));
         c->fbs[i].is_clear = true; c->fbs[i].last_lane = -1;
     }
@@ -509,6 +516,8 @@ void gs4d_destroy(gs4d_ctx* c) {
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
         if (c->fbs[i].mem) (void)hipFree(c->fbs[i].mem);
+        if (c->fbs[i].linecnt) (void)hipFree(c->fbs[i].linecnt);
+        if (L.line_verts) (void)hipFree(L.line_verts);
         if (L.order_copy) (void)hipFree(L.order_copy);
         if (L.proj) (void)hipFree(L.proj);
         if (L.rects) (void)hipFree(L.rects);
@@ -794,6 +803,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
                 a.ks = ob->prov_ks; a.keybits = ob->prov_bits; ok = true;
             }
         }
+        if (ok && (nkeys > V2_MAX_RECORDS || (a.mode == GS4D_MODE_4D_SORTED && a.instances > V2_MAX_RECORDS) || (size_t)c->tiles_x * c->tiles_y > 256u * 1024u)) ok = false;   // tilelist.hip's entry format
         if (ok && c->long_lists) {
             // the lists were too long last time: stay on the ordered path, but probe again now and then if they look short on average
             const uint64_t tiles = (uint64_t)c->tiles_x * c->tiles_y;
@@ -825,6 +835,43 @@ int gs4d_draw_quads(gs4d_ctx* c, gs4d_buf vertices, size_t nquads) {
     if (c->mode != GS4D_MODE_3D_FULL) return fail(c, GS4D_E_INVALID, "draw_quads: mode must be GS4D_MODE_3D_FULL");
     DrawArgs a; a.mode = c->mode; a.u = c->u; a.instances = nquads; a.quads = true; a.data = vertices; a.order = 0;
     return draw_common(c, a);
+}
+
+// ---- overlay lines (Renderer.cpp:41-215) ----
+int gs4d_draw_lines(gs4d_ctx* c, const float* verts, size_t nverts, int dims, int strip, const float viewproj[16], const float rgba[4], float width) {
+    if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    if (dims != 2 && dims != 3) return fail(c, GS4D_E_INVALID, "draw_lines: dims must be 2 (NDC positions) or 3 (positions transformed by viewproj)");
+    if (!rgba || (dims == 3 && !viewproj) || (nverts && !verts)) return fail(c, GS4D_E_INVALID, "draw_lines: NULL argument");
+    if (nverts < 2) return GS4D_OK;
+    if (nverts > 0x7FFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw_lines: too many vertices");
+    // lines blend into the image in call order: a splat draw into it that still awaits validation (and may be re-run) goes first
+    int rc = resolve_image(c, c->cur_fb); if (rc) return rc;
+    rc = after_user_stream(c); if (rc) return rc;
+    rc = materialise_fb(c); if (rc) return rc;
+    Framebuffer& F = c->fbs[c->cur_fb];
+    rc = fb_access(c, F); if (rc) return rc;
+    Lane& L = lane(c);
+    if (!F.linecnt) {
+        HIPCHK(c, hipMalloc(&F.linecnt, (size_t)c->W * c->H * 4));
+        HIPCHK(c, hipMemsetAsync(F.linecnt, 0, (size_t)c->W * c->H * 4, L.s));
+    }
+    const size_t floats = nverts * (size_t)dims;
+    if (L.line_cap < floats) {
+        HIPCHK(c, hipStreamSynchronize(L.s));
+        if (L.line_verts) (void)hipFree(L.line_verts);
+        L.line_verts = nullptr; L.line_cap = 0;
+        HIPCHK(c, hipMalloc(&L.line_verts, std::max<size_t>(floats, 4096) * 4));
+        L.line_cap = std::max<size_t>(floats, 4096);
+    }
+    HIPCHK(c, hipMemcpyAsync(L.line_verts, verts, floats * 4, hipMemcpyHostToDevice, L.s));     // the caller's array is reusable on return (pageable source)
+    LineParams p;
+    for (int i = 0; i < 16; ++i) p.vp[i] = viewproj ? viewproj[i] : (i % 5 == 0 ? 1.0f : 0.0f);
+    for (int i = 0; i < 4; ++i) p.rgba[i] = rgba[i];
+    p.W = c->W; p.H = c->H;
+    HIPCHK(c, launch_lines(L.s, L.line_verts, nverts, dims, strip ? 1 : 0, p, width, F.linecnt, F.mem));
+    ++c->ops;
+    return GS4D_OK;
 }
 
 // ---- read-back ----

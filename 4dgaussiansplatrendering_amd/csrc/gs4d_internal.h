@@ -104,24 +104,31 @@ struct KeySrc {
     float vr0 = 0, vr1 = 0, vr2 = 0, vr3 = 0;   // view row 2 at keygen time (KEYSRC_VIEWZ)
     uint32_t bias = 0;                           // subtracted from the key's bit pattern (host-proven lower bound, as in the depth sort)
 };
-struct TileCount {                               // tcount == nullptr: the ordered path (no counting in the projection kernel)
-    uint32_t* tcount = nullptr;                  // [tiles] entries per tile; all-zero between draws (k_tilescan clears what it reads)
+struct TileCount {                               // hist == nullptr: the ordered path (no counting in the projection kernel)
+    uint32_t* hist = nullptr;                    // [rows][nb]: entries that the records of segment `row` put into bucket b = tile % nb
     uint32_t* skey = nullptr;                    // [records] blend-order key of every record
+    uint32_t nb = 0, seg = 0;                    // buckets (a power of two), records per segment (a multiple of 256; one workgroup walks one segment)
     int tiles_x = 0, shard_rank = 0, shard_world = 1;
     KeySrc ks;
 };
 constexpr uint32_t V2_MAX_LIST = 2048;           // longest per-tile list the compositor sorts in LDS; beyond it a draw uses the ordered path
+constexpr uint32_t V2_MAX_RECORDS = 1u << 24;    // an entry carries (tile / nb) in the top byte of its record word
 struct TileLists {
-    uint32_t* tcount = nullptr; uint32_t* tstart = nullptr; uint32_t* cursor = nullptr; size_t tiles_cap = 0;   // one allocation
+    uint32_t* hist = nullptr; size_t hist_cap = 0;            // [rows][nb] counts, turned in place into the first entry slot of every (segment, bucket) run
+    uint32_t* bbase = nullptr; uint32_t* tstart = nullptr; uint32_t* tcnt = nullptr; size_t tiles_cap = 0, nb_cap = 0;   // [nb + 1] bucket starts; per tile: first entry, entries
     uint32_t* skey = nullptr; size_t skey_cap = 0;
+    uint32_t nb = 0, rows = 0, seg = 0;                       // geometry of the current draw (tile_lists_plan)
 };
+// false: this frame / record count cannot use the unordered path (more than 256 * 1024 tiles, or 2^24 records)
+bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords);
 hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_t nrecords);
 void tile_lists_free(TileLists& t);
-// total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list;
-// total_host (pinned, mapped) receives [0..3] and the longest list at [5]
-hipError_t launch_tilescan(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, size_t cap, uint32_t hint);
-hipError_t launch_tile_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* entries, int tiles_x, int shard_rank, int shard_world);
-hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
+// total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list,
+// [6] workgroups of k_bucket_tiles that have finished; total_host (pinned, mapped) receives [0..3] and the longest list at [5]
+hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap);
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
+hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, const uint2* tmp, uint2* entries, uint32_t hint);
+hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits);
 
 #ifdef __HIPCC__
@@ -176,5 +183,10 @@ hipError_t launch_fill(hipStream_t st, float4* fb, size_t npix, const float clea
 hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, size_t npix, uint32_t* out);
 // the pixel rows of the tile rows ty % world == rank, top of the band = the context's first tile row; band_rows pixel rows in all
 hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, int W, int H, int rank, int world, int band_rows, uint32_t* out);
+
+// ---- lines.hip ----
+struct LineParams { float vp[16]; float rgba[4]; int W, H; };
+// verts_dev: nverts positions of `dims` floats on the device; cnt: W*H fragment counters, all-zero between calls
+hipError_t launch_lines(hipStream_t st, const float* verts_dev, size_t nverts, int dims, int strip, const LineParams& p, float width, uint32_t* cnt, float4* fb);
 
 } // namespace gs4d

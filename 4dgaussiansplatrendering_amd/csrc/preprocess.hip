@@ -147,14 +147,13 @@ __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid,
     return make_uint2(rect0, rect1);
 }
 
-// Unordered draw path: the projection kernel also counts, per 8x8 tile, the entries its records will put on the tile lists (plain
-// no-return atomics, nothing waits for them) and stores each record's blend-order key.  Called by every lane of the wave that is still
-// alive (lanes past the end have returned): footprints of more than 16 tiles are counted by the whole wave.
-__device__ __forceinline__ void count_tiles(const TileCount& tc, uint32_t i, uint2 rect, uint32_t key) {
-    tc.skey[i] = key;
-    const TRect r = tile_rect(rect.x, rect.y, (uint32_t)tc.shard_rank, (uint32_t)tc.shard_world);
+// Unordered draw path (tilelist.hip): the projection kernel also counts, per bucket b = tile % nb, the tile-list entries of the segment
+// of records its workgroup walks (LDS atomics; the row of counts is stored once at the end) and stores each record's blend-order key.
+// Called by all 64 lanes of the wave (`r.count` == 0 for lanes without a record): footprints of more than 16 tiles are counted by the
+// whole wave.
+__device__ __forceinline__ void count_buckets(uint32_t* h, uint32_t nbm, uint32_t tiles_x, const TRect& r) {
     const bool big = r.count > 16u;
-    if (!big) for (uint32_t j = 0; j < r.count; ++j) atomicAdd(&tc.tcount[tile_of(r, j, (uint32_t)tc.tiles_x)], 1u);
+    if (!big) for (uint32_t j = 0; j < r.count; ++j) atomicAdd(&h[tile_of(r, j, tiles_x) & nbm], 1u);
     uint64_t m = __ballot(big);
     const uint32_t lane = threadIdx.x & 63u;
     while (m) {
@@ -163,7 +162,7 @@ __device__ __forceinline__ void count_tiles(const TileCount& tc, uint32_t i, uin
         TRect rr;
         rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
         rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
-        for (uint32_t j = lane; j < rr.count; j += 64u) atomicAdd(&tc.tcount[tile_of(rr, j, (uint32_t)tc.tiles_x)], 1u);
+        for (uint32_t j = lane; j < rr.count; j += 64u) atomicAdd(&h[tile_of(rr, j, tiles_x) & nbm], 1u);
     }
 }
 
@@ -235,9 +234,13 @@ __device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict__ soa, uint32_t n, PU u, PreOut out, TileCount tc) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
+// One record each: returns its pixel rectangle, and through `key` its blend-order key (unordered path).
+struct Src4D { const float4* soa; };
+struct Src3D { const float* verts; };
+struct Src2D { const float* recs; };
+
+__device__ __forceinline__ uint2 project_record(const Src4D& src, uint32_t n, uint32_t i, const PU& u, const PreOut& out, const KeySrc& ks, uint32_t& key) {
+    const float4* __restrict__ soa = src.soa;
     const float4 pos = soa[i], col = soa[(size_t)n + i];
     const float4 s0 = soa[(size_t)2 * n + i], s1 = soa[(size_t)3 * n + i], s2 = soa[(size_t)4 * n + i], s3 = soa[(size_t)5 * n + i];
     float s44 = s3.w;
@@ -257,14 +260,12 @@ __global__ __launch_bounds__(256) void k_preprocess_4d(const float4* __restrict_
         for (int r = 0; r < 3; ++r) C[c][r] = S[c][r] - a[r] * tv[c];              // :89-95
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, mx, my, mz, C, q, ncx, ncy);
-    const uint2 rect = emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w);
-    if (tc.tcount) count_tiles(tc, i, rect, blend_key_4d(tc.ks, i, pos, s3));
+    key = blend_key_4d(ks, i, pos, s3);
+    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w);
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__ verts, uint32_t n, PU u, PreOut out, TileCount tc) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float* v = verts + (size_t)72 * i;      // vertex 0 of the quad: {vpos2, spos3, col4, sig9}
+__device__ __forceinline__ uint2 project_record(const Src3D& src, uint32_t, uint32_t i, const PU& u, const PreOut& out, const KeySrc&, uint32_t& key) {
+    const float* v = src.verts + (size_t)72 * i;      // vertex 0 of the quad: {vpos2, spos3, col4, sig9}
     float C[3][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -272,14 +273,12 @@ __global__ __launch_bounds__(256) void k_preprocess_3d(const float* __restrict__
         for (int r = 0; r < 3; ++r) C[c][r] = v[9 + 3 * c + r];
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, v[2], v[3], v[4], C, q, ncx, ncy);
-    const uint2 rect = emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8]);
-    if (tc.tcount) count_tiles(tc, i, rect, i);
+    key = i;
+    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8]);
 }
 
-__global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__ recs, uint32_t n, PU u, PreOut out, TileCount tc) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const float* rec = recs + (size_t)12 * i;
+__device__ __forceinline__ uint2 project_record(const Src2D& src, uint32_t, uint32_t i, const PU& u, const PreOut& out, const KeySrc&, uint32_t& key) {
+    const float* rec = src.recs + (size_t)12 * i;
     const float* P = u.P;
     float x = rec[0], y = rec[1];
     float psx = ((P[0] * x + P[4] * y) + P[8] * -1.0f) + P[12] * 1.0f;             // Splat2DVSI.GLSL:64
@@ -297,8 +296,38 @@ __global__ __launch_bounds__(256) void k_preprocess_2d(const float* __restrict__
     float clipz = P[10] * zc + P[14] * wc4;
     bool valid = (clipw > 0.0f) && !(clipz < -clipw || clipz > clipw);
     float kx = P[0] / clipw, ky = P[5] / clipw;
-    const uint2 rect = emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
-    if (tc.tcount) count_tiles(tc, i, rect, i);
+    key = i;
+    return emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
+}
+
+// COUNT == false: one thread per record (the ordered path).  COUNT == true: workgroup w walks records [w * seg, (w + 1) * seg), 256 per
+// round, and leaves row w of the bucket histogram.
+template <class SRC, bool COUNT>
+__global__ __launch_bounds__(256) void k_preprocess(SRC src, uint32_t n, PU u, PreOut out, TileCount tc) {
+    if (!COUNT) {
+        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+        if (i >= n) return;
+        uint32_t key;
+        (void)project_record(src, n, i, u, out, tc.ks, key);
+        return;
+    }
+    __shared__ uint32_t h[1024];
+    for (uint32_t b = threadIdx.x; b < tc.nb; b += 256u) h[b] = 0u;
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * tc.seg, i1 = min(n, i0 + tc.seg);
+    for (uint32_t ib = i0; ib < i1; ib += 256u) {           // uniform trip count: every lane stays for the wave-wide counting
+        const uint32_t i = ib + threadIdx.x;
+        TRect r{ 0u, 0u, 0u, 0u, 1u, 0u };
+        if (i < i1) {
+            uint32_t key;
+            const uint2 rect = project_record(src, n, i, u, out, tc.ks, key);
+            tc.skey[i] = key;
+            r = tile_rect(rect.x, rect.y, (uint32_t)tc.shard_rank, (uint32_t)tc.shard_world);
+        }
+        count_buckets(h, tc.nb - 1u, (uint32_t)tc.tiles_x, r);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < tc.nb; b += 256u) tc.hist[(size_t)blockIdx.x * tc.nb + b] = h[b];
 }
 
 static PU make_pu(const Uniforms& un, int W, int H) {
@@ -308,20 +337,15 @@ static PU make_pu(const Uniforms& un, int W, int H) {
     return u;
 }
 
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
+template <class SRC>
+static hipError_t launch_pre(hipStream_t st, SRC src, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
     if (n == 0) return hipSuccess;
-    k_preprocess_4d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(soa, (uint32_t)n, make_pu(un, W, H), out, tc);
+    if (tc.hist) k_preprocess<SRC, true><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    else k_preprocess<SRC, false><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
-    if (n == 0) return hipSuccess;
-    k_preprocess_3d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(verts72, (uint32_t)n, make_pu(un, W, H), out, tc);
-    return hipGetLastError();
-}
-hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
-    if (n == 0) return hipSuccess;
-    k_preprocess_2d<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(rec48, (uint32_t)n, make_pu(un, W, H), out, tc);
-    return hipGetLastError();
-}
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src4D{ soa }, n, un, W, H, out, tc); }
+hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src3D{ verts72 }, n, un, W, H, out, tc); }
+hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src2D{ rec48 }, n, un, W, H, out, tc); }
 
 } // namespace gs4d

@@ -1,17 +1,27 @@
-// tilelist.hip — per-tile splat lists for the unordered draw path: count -> scan -> scatter, no workgroup ever waits for another.
+// tilelist.hip — per-tile splat lists for the unordered draw path.  No workgroup waits for another, no global atomics.
 //
 // The reference has no tiles: the hardware rasteriser walks the instances in order and the ROP blends in that order
 // (Renderer.cpp:33-39 -> glDrawElementsInstanced; Application.cpp:150-154).  The ordered path (binning.hip) reproduces that order by
 // emitting (tile, record) entries in instance order — a chained scan — and stable-sorting them by tile: four launches, three of
-// them chained scans whose cost at 10^6 splats is hand-off latency, not bandwidth.  Here the order is restored where it is consumed:
-//   k_preprocess_* (preprocess.hip) counts the entries of every tile with no-return atomics while it projects the records,
-//   k_tilescan     turns the counts into list starts (one workgroup; 32 400 tiles at 1080p) and validates capacity and list length,
-//   k_tile_scatter puts (blend-order key, record) on the lists in whatever order its returning atomics resolve,
-//   k_composite_v2 (composite2.hip) sorts each tile's list by (key, record) in LDS before it blends.
-// Which key gives "instance order" is decided on the host (KeySrc, gs4d_internal.h): the record index when instance k draws record k,
-// the depth key when the bound sort index is the library's own sort of gs4d_keygen's keys (the sort index is then never read).
-// Lists longer than the compositor can hold, or more entries than the preallocated capacity, raise a flag in k_tilescan: the
-// scatter and the compositor then do nothing and the host re-runs the draw (larger capacity, longer lists, or the ordered path).
+// them chained scans whose cost at 10^6 splats is hand-off latency, not bandwidth.  Here the order is restored where it is consumed
+// (composite2.hip sorts each tile's list by (key, record) in LDS), so the lists may be built in ANY order — a two-level bucket
+// sort by tile id in which every write position is computed, never negotiated:
+//
+//   bucket b = tile % nb   (interleaved: the dense image centre spreads over all buckets),   nb a power of two, tile / nb < 256
+//
+//   k_preprocess<.., true>  (preprocess.hip) walks segment w of the records (one workgroup, `seg` records) and leaves
+//                           hist[w][b] = entries its records put into bucket b            (LDS atomics, one plain row store)
+//   k_bucket_scan           column-wise exclusive scan: hist[w][b] becomes the first slot of run (w, b); bucket starts; capacity check
+//   k_bucket_scatter        walks the same segments again: entry -> tmp[run start + LDS counter]   (key, tile/nb << 24 | record)
+//   k_bucket_tiles          one workgroup per bucket: counts its entries per tile in LDS, writes the tile table (first entry, count)
+//                           and moves the entries to their tile's list; the longest list is checked against the compositor's capacity
+//   k_composite_v2          (composite2.hip)
+//
+// (A first version counted entries per tile with global atomics in the projection kernel and scattered with returning atomics:
+// 1.4e6 device-scope atomics cost 150 us each way on MI355X — they execute at the memory side, ~9e9/s when scattered.  Hence this.)
+// Which key gives "instance order" is decided on the host (KeySrc, gs4d_internal.h).  Lists longer than the compositor can hold, or
+// more entries than the preallocated capacity, raise a flag: the later kernels then do nothing and the host re-runs the draw
+// (larger capacity, longer lists, or the ordered path).
 #include "gs4d_internal.h"
 #include <algorithm>
 
@@ -21,79 +31,180 @@ typedef unsigned long long u64;
 
 constexpr int SCAN_THREADS = 1024;
 
-// tstart[t] = number of entries on the lists of tiles < t; cursor[t] = the same (the scatter's running position); tcount cleared.
-__global__ __launch_bounds__(SCAN_THREADS) void k_tilescan(uint32_t* __restrict__ tcount, uint32_t ntiles, uint32_t* __restrict__ tstart, uint32_t* __restrict__ cursor,
-                                                           uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t cap, uint32_t hint) {
+// hist[w][b] (counts) -> first entry slot of run (w, b): runs of one bucket are laid out in segment order, buckets in index order.
+__global__ __launch_bounds__(SCAN_THREADS) void k_bucket_scan(uint32_t* __restrict__ hist, uint32_t rows, uint32_t nb, uint32_t* __restrict__ bbase,
+                                                              uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t cap) {
+    __shared__ u64 part[SCAN_THREADS];             // [row group][column]
     __shared__ u64 wsum[SCAN_THREADS / 64];
-    __shared__ uint32_t wmax[SCAN_THREADS / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t per = (ntiles + SCAN_THREADS - 1u) / SCAN_THREADS;
-    const uint32_t t0 = min(tid * per, ntiles), t1 = min(t0 + per, ntiles);
-    u64 sum = 0; uint32_t mx = 0;
-    for (uint32_t t = t0; t < t1; ++t) { const uint32_t c = tcount[t]; sum += c; mx = max(mx, c); }
-    u64 inc = sum;
+    const uint32_t groups = SCAN_THREADS / nb;     // nb <= 1024
+    const uint32_t col = tid % nb, grp = tid / nb;
+    const uint32_t per = (rows + groups - 1u) / groups;
+    const uint32_t r0 = min(grp * per, rows), r1 = min(r0 + per, rows);
+    u64 sum = 0;
+    if (grp < groups) for (uint32_t r = r0; r < r1; ++r) sum += hist[(size_t)r * nb + col];
+    part[tid] = grp < groups ? sum : 0ull;
+    __syncthreads();
+    // column totals (threads 0..nb-1), exclusive scan over the columns
+    u64 colsum = 0;
+    if (tid < nb) for (uint32_t g = 0; g < groups; ++g) colsum += part[g * nb + tid];
+    u64 inc = tid < nb ? colsum : 0ull;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const u64 v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
     if (lane == 63u) wsum[w] = inc;
-    if (lane == 0u) wmax[w] = mx;
     __syncthreads();
-    u64 base = 0, grand = 0; uint32_t gmax = 0;
+    u64 base = 0, grand = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_THREADS / 64; ++k) { const u64 s = wsum[k]; if ((unsigned)k < w) base += s; grand += s; gmax = max(gmax, wmax[k]); }
-    u64 run = base + inc - sum;
-    const bool over = grand > (u64)cap;
-    for (uint32_t t = t0; t < t1; ++t) {
-        const uint32_t c = tcount[t];
-        const uint32_t r32 = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;     // only meaningful when the draw is not aborted
-        tstart[t] = r32; cursor[t] = r32; tcount[t] = 0u;
-        run += c;
+    for (int k = 0; k < SCAN_THREADS / 64; ++k) { const u64 s = wsum[k]; if ((unsigned)k < w) base += s; grand += s; }
+    const u64 cstart = base + inc - colsum;        // first slot of bucket `tid`
+    __syncthreads();
+    if (tid < nb) {
+        bbase[tid] = cstart > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cstart;
+        // first slot of every row group of this column (reusing part[])
+        u64 run = cstart;
+        for (uint32_t g = 0; g < groups; ++g) { const u64 c = part[g * nb + tid]; part[g * nb + tid] = run; run += c; }
+    }
+    __syncthreads();
+    if (grp < groups) {
+        u64 run = part[tid];
+        for (uint32_t r = r0; r < r1; ++r) {
+            const size_t o = (size_t)r * nb + col;
+            const uint32_t c = hist[o];
+            hist[o] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;     // only meaningful when the draw is not aborted
+            run += c;
+        }
     }
     if (tid == 0) {
         const uint32_t sat = grand > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)grand;
-        const uint32_t flags = (over ? 1u : 0u) | (gmax > hint ? 2u : 0u);
-        tstart[ntiles] = sat;
-        total[0] = sat; total[1] = flags; total[2] = (uint32_t)grand; total[3] = (uint32_t)(grand >> 32); total[4] = gmax;
-        total_host[0] = sat; total_host[1] = flags; total_host[2] = (uint32_t)grand; total_host[3] = (uint32_t)(grand >> 32); total_host[5] = gmax;
+        const uint32_t flags = grand > (u64)cap ? 1u : 0u;
+        bbase[nb] = sat;
+        total[0] = sat; total[1] = flags; total[2] = (uint32_t)grand; total[3] = (uint32_t)(grand >> 32); total[4] = 0u; total[6] = 0u;
+        // an aborted draw stops here: tell the host now (otherwise k_bucket_tiles reports, once the longest list is known)
+        if (flags) { total_host[0] = sat; total_host[1] = flags; total_host[2] = (uint32_t)grand; total_host[3] = (uint32_t)(grand >> 32); total_host[5] = 0u; }
     }
 }
 
-// One thread per record: (key, record) onto the list of every tile its pixel rectangle touches.  The position inside a list is
-// whatever the returning atomic hands out — the compositor orders the list.
-__global__ __launch_bounds__(256) void k_tile_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t n, uint32_t* __restrict__ cursor,
-                                                      const uint32_t* __restrict__ total, uint2* __restrict__ entries, uint32_t tiles_x, uint32_t shard_rank, uint32_t shard_world) {
-    if (total[1]) return;                                  // aborted draw: positions may lie beyond the capacity
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint2 rc = rects[i];
-    const TRect r = tile_rect(rc.x, rc.y, shard_rank, shard_world);
-    const uint32_t key = r.count ? skey[i] : 0u;
-    const bool big = r.count > 16u;
-    if (!big) for (uint32_t j = 0; j < r.count; ++j) { const uint32_t pos = atomicAdd(&cursor[tile_of(r, j, tiles_x)], 1u); entries[pos] = make_uint2(key, i); }
-    uint64_t m = __ballot(big);
-    const uint32_t lane = threadIdx.x & 63u;
-    while (m) {                                            // large footprints: the whole wave writes one record's entries
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1ull;
-        TRect rr;
-        rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
-        rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
-        const uint32_t key2 = __shfl(key, src, 64), rec2 = __shfl(i, src, 64);
-        for (uint32_t j = lane; j < rr.count; j += 64u) { const uint32_t pos = atomicAdd(&cursor[tile_of(rr, j, tiles_x)], 1u); entries[pos] = make_uint2(key2, rec2); }
+// Segment w again: every entry goes to tmp[run start of (w, bucket) + a counter in LDS].  256 threads, one record each per round.
+__global__ __launch_bounds__(256) void k_bucket_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t n, uint32_t seg, uint32_t nb,
+                                                        const uint32_t* __restrict__ offs, const uint32_t* __restrict__ total, uint2* __restrict__ tmp,
+                                                        uint32_t tiles_x, uint32_t shard_rank, uint32_t shard_world) {
+    __shared__ uint32_t cur[1024];
+    if (total[1] & 1u) return;                             // aborted draw: slots may lie beyond the capacity
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t b = tid; b < nb; b += 256u) cur[b] = offs[(size_t)blockIdx.x * nb + b];
+    __syncthreads();
+    const uint32_t nbm = nb - 1u, nbs = (uint32_t)__ffs((int)nb) - 1u;
+    const uint32_t i0 = blockIdx.x * seg, i1 = min(n, i0 + seg);
+    for (uint32_t ib = i0; ib < i1; ib += 256u) {          // uniform trip count: every lane stays to the end
+        const uint32_t i = ib + tid;
+        TRect r{ 0u, 0u, 0u, 0u, 1u, 0u };
+        uint32_t key = 0u;
+        if (i < i1) { const uint2 rc = rects[i]; r = tile_rect(rc.x, rc.y, shard_rank, shard_world); if (r.count) key = skey[i]; }
+        const bool big = r.count > 16u;
+        if (!big) for (uint32_t j = 0; j < r.count; ++j) {
+            const uint32_t t = tile_of(r, j, tiles_x);
+            const uint32_t pos = atomicAdd(&cur[t & nbm], 1u);
+            tmp[pos] = make_uint2(key, ((t >> nbs) << 24) | i);
+        }
+        uint64_t m = __ballot(big);
+        while (m) {                                        // large footprints: the whole wave writes one record's entries
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            TRect rr;
+            rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
+            rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
+            const uint32_t key2 = __shfl(key, src, 64), rec2 = __shfl(i, src, 64);
+            for (uint32_t j = lane; j < rr.count; j += 64u) {
+                const uint32_t t = tile_of(rr, j, tiles_x);
+                const uint32_t pos = atomicAdd(&cur[t & nbm], 1u);
+                tmp[pos] = make_uint2(key2, ((t >> nbs) << 24) | rec2);
+            }
+        }
     }
+}
+
+// Bucket b -> the lists of its tiles (tile = h * nb + b, h < 256).  Two sweeps over the bucket's entries: count per tile, then place.
+__global__ __launch_bounds__(1024) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles,
+                                                       uint32_t* __restrict__ tstart, uint32_t* __restrict__ tcnt, uint2* __restrict__ entries,
+                                                       uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t hint) {
+    __shared__ uint32_t cnt[256];
+    __shared__ uint32_t cur[256];
+    __shared__ uint32_t ws[4];
+    if (total[1] & 1u) return;                             // capacity overflow (set by k_bucket_scan); bit 1 is raised HERE by other workgroups and must not stop this one
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
+    const uint32_t lo = bbase[b], hi = bbase[b + 1];
+    if (tid < 256u) cnt[tid] = 0u;
+    __syncthreads();
+    for (uint32_t i = lo + tid; i < hi; i += 1024u) atomicAdd(&cnt[tmp[i].y >> 24], 1u);
+    __syncthreads();
+    uint32_t c = 0, inc = 0;
+    if (tid < 256u) {
+        c = cnt[tid]; inc = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
+        if (lane == 63u) ws[w] = inc;
+    }
+    __syncthreads();
+    if (tid < 256u) {
+        uint32_t base = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) if ((unsigned)k < w) base += ws[k];
+        const uint32_t first = lo + base + inc - c;
+        cur[tid] = first;
+        const uint32_t tile = tid * nb + b;
+        if (tile < ntiles) { tstart[tile] = first; tcnt[tile] = c; }
+        uint32_t mx = c;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
+        if (lane == 0u && mx) { atomicMax(&total[4], mx); if (mx > hint) atomicOr(&total[1], 2u); }
+    }
+    __syncthreads();
+    for (uint32_t i = lo + tid; i < hi; i += 1024u) {
+        const uint2 e = tmp[i];
+        const uint32_t pos = atomicAdd(&cur[e.y >> 24], 1u);
+        entries[pos] = make_uint2(e.x, e.y & 0x00FFFFFFu);
+    }
+    // the last workgroup to finish reports to the host (pinned, mapped memory behind the lane's event)
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (atomicAdd(&total[6], 1u) == gridDim.x - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const uint32_t flags = __hip_atomic_load(&total[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t longest = __hip_atomic_load(&total[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = longest; total_host[1] = flags;
+        }
+    }
+}
+
+bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords) {
+    if (nrecords == 0 || nrecords > V2_MAX_RECORDS) return false;
+    uint32_t nb = 64;
+    while ((size_t)nb * 256 < ntiles && nb < 1024) nb *= 2;
+    if ((size_t)nb * 256 < ntiles) return false;
+    size_t rows = std::min<size_t>((nrecords + 1023) / 1024, 1024);
+    size_t seg = ((nrecords + rows - 1) / rows + 255) / 256 * 256;
+    rows = (nrecords + seg - 1) / seg;
+    t.nb = nb; t.rows = (uint32_t)rows; t.seg = (uint32_t)seg;
+    return true;
 }
 
 hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_t nrecords) {
     hipError_t e;
-    if (t.tiles_cap < ntiles) {
-        if (t.tcount) { (void)hipStreamSynchronize(st); (void)hipFree(t.tcount); }
-        t.tcount = t.tstart = t.cursor = nullptr; t.tiles_cap = 0;
-        const size_t words = 3 * ntiles + 4;
-        if ((e = hipMalloc(&t.tcount, words * 4)) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(t.tcount, 0, words * 4, st)) != hipSuccess) return e;      // the counts stay zero between draws: k_tilescan clears what it reads
-        t.tstart = t.tcount + ntiles; t.cursor = t.tstart + ntiles + 1;
-        t.tiles_cap = ntiles;
+    const size_t hist_words = (size_t)t.rows * t.nb;
+    if (t.hist_cap < hist_words) {
+        if (t.hist) { (void)hipStreamSynchronize(st); (void)hipFree(t.hist); }
+        t.hist = nullptr; t.hist_cap = 0;
+        if ((e = hipMalloc(&t.hist, hist_words * 4)) != hipSuccess) return e;
+        t.hist_cap = hist_words;
+    }
+    if (t.tiles_cap < ntiles || t.nb_cap < t.nb) {
+        if (t.bbase) { (void)hipStreamSynchronize(st); (void)hipFree(t.bbase); }
+        t.bbase = t.tstart = t.tcnt = nullptr;
+        const size_t nt = std::max(ntiles, t.tiles_cap), nbc = std::max<size_t>(t.nb, t.nb_cap);
+        if ((e = hipMalloc(&t.bbase, (nbc + 1 + 2 * nt) * 4)) != hipSuccess) return e;
+        t.tstart = t.bbase + nbc + 1; t.tcnt = t.tstart + nt;
+        t.tiles_cap = nt; t.nb_cap = nbc;
     }
     if (t.skey_cap < nrecords) {
         if (t.skey) { (void)hipStreamSynchronize(st); (void)hipFree(t.skey); }
@@ -105,20 +216,24 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
 }
 
 void tile_lists_free(TileLists& t) {
-    if (t.tcount) (void)hipFree(t.tcount);
+    if (t.hist) (void)hipFree(t.hist);
+    if (t.bbase) (void)hipFree(t.bbase);
     if (t.skey) (void)hipFree(t.skey);
     t = TileLists();
 }
 
-hipError_t launch_tilescan(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, size_t cap, uint32_t hint) {
-    // the list starts are laid out for `tiles_cap` tiles (tstart has tiles_cap + 1 words): a smaller frame uses a prefix
-    k_tilescan<<<dim3(1), dim3(SCAN_THREADS), 0, st>>>(t.tcount, (uint32_t)ntiles, t.tstart, t.cursor, total, total_host, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFull), hint);
+hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap) {
+    k_bucket_scan<<<dim3(1), dim3(SCAN_THREADS), 0, st>>>(t.hist, t.rows, t.nb, t.bbase, total, total_host, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFull));
     return hipGetLastError();
 }
 
-hipError_t launch_tile_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* entries, int tiles_x, int shard_rank, int shard_world) {
-    if (nrecords == 0) return hipSuccess;
-    k_tile_scatter<<<dim3((unsigned)((nrecords + 255) / 256)), dim3(256), 0, st>>>(rects, t.skey, (uint32_t)nrecords, t.cursor, total, entries, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
+    k_bucket_scatter<<<dim3(t.rows), dim3(256), 0, st>>>(rects, t.skey, (uint32_t)nrecords, t.seg, t.nb, t.hist, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, const uint2* tmp, uint2* entries, uint32_t hint) {
+    k_bucket_tiles<<<dim3(t.nb), dim3(1024), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.tstart, t.tcnt, entries, total, total_host, hint);
     return hipGetLastError();
 }
 

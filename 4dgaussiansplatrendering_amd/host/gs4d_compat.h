@@ -1,18 +1,22 @@
 // gs4d_compat.h — C++ mirror of the reference's host classes on this path, implemented over the C ABI (include/gs4d.h).
 //
-// Same class names, method names, argument meaning and error behaviour as the reference, so that a scene written against
-// the reference (Scenes.h:226-340) drives the HIP renderer unchanged:
+// Same class names, method names, argument meaning and error behaviour as the reference, so that the reference's own scene code
+// (4DSplatRendering/Splat.h, Scene.h, Scenes.h — unmodified) drives the HIP renderer:
 //   ShareStorageBuffer            4DSplatRendering/ShareStorageBuffer.h:13-21, .cpp:3-40
 //   Shader                        4DSplatRendering/Shader.h:28-72  (AddShaderSource/BuildShader/Bind/SetUniform*)
-//   Renderer                      4DSplatRendering/Renderer.h:37-39, .cpp:20-39 (Clear, Draw, Draw instanced)
+//   Renderer                      4DSplatRendering/Renderer.h:27-50, .cpp:20-215 (Clear, Draw, Draw instanced, DrawLine/DrawGrid/DrawAxis)
 //   radix_sort::sorter            Dependencies/GPU_RADIX_SORT/radix_sort.hpp:219, 258
-//   VertexBuffer/IndexBuffer/VertexArray/VertexBufferLayout, Geometry::Quad   (API shape only: the unit quad is implicit)
-//   Camera                        4DSplatRendering/Camera.h:29-54, .cpp:50-63
+//   VertexBuffer/IndexBuffer/VertexArray/VertexBufferLayout, Geometry::*   VertexBuffer.h, IndexBuffer.h, VertexArray.h, VertexBufferLayout.h, Geometry.h
+//   Camera                        4DSplatRendering/Camera.h:16-85, .cpp:5-239 (getters, setters, HandleInput as a state machine)
 //   raw GL used by the scenes     glGenBuffers/glBindBuffer/glBufferStorage/glBufferSubData/glBindBufferBase/glDeleteBuffers
 //                                 (Scenes.h:241-247, 282-283, 321-325, 336, 220-224) + glClearColor/glBlendFunc/glViewport
 // No OpenGL behind it: buffer "names" are gs4d_buf handles of the current gs4d context (gs4d::compat::MakeCurrent).
-// Matrix/vector arguments are templates: anything laid out like glm::mat4 / glm::vec3 (column-major floats) works, so a
-// maintainer keeps passing GLM types; gs4d::compat::mat4/vec3 are provided for builds without GLM.
+//
+// Two ways to use it.  (1) With the reference tree: host/shadow/ holds one forwarding header per reference header this file
+// replaces (Shader.h, Renderer.h, Camera.h, Geometry.h, VertexArray.h, VertexBuffer.h, IndexBuffer.h, VertexBufferLayout.h,
+// ShareStorageBuffer.h, radix_sort.hpp, GLEW/glew.h, GLFW/glfw3.h, imgui.h); copied over the reference's files of the same names
+//  the rest of the tree compiles unchanged, and with GLM on the include path every vector / matrix in this file IS the
+// glm type.  (2) Without GLM (host/scene_replay.cpp, the GPU box): small stand-in vec/mat structs with the same layout.
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -23,11 +27,26 @@
 #include <vector>
 #include "../../include/gs4d.h"
 
+#if !defined(GS4D_COMPAT_NO_GLM) && defined(__has_include)
+#if __has_include(<glm/glm.hpp>)
+#define GS4D_COMPAT_GLM 1
+#include <glm/glm.hpp>
+#endif
+#endif
+
 namespace gs4d { namespace compat {
 
-struct vec3 { float x, y, z; vec3(float a = 0, float b = 0, float c = 0) : x(a), y(b), z(c) {} float& operator[](int i) { return (&x)[i]; } };
-struct vec4 { float x, y, z, w; };
+#ifdef GS4D_COMPAT_GLM
+using vec2 = glm::vec2; using vec3 = glm::vec3; using vec4 = glm::vec4; using mat2 = glm::mat2; using mat3 = glm::mat3; using mat4 = glm::mat4;
+#else
+struct vec2 { float x, y; vec2(float a = 0, float b = 0) : x(a), y(b) {} float& operator[](int i) { return (&x)[i]; } const float& operator[](int i) const { return (&x)[i]; } };
+struct vec3 { float x, y, z; vec3(float a = 0, float b = 0, float c = 0) : x(a), y(b), z(c) {} float& operator[](int i) { return (&x)[i]; } const float& operator[](int i) const { return (&x)[i]; } };
+struct vec4 { float x, y, z, w; vec4(float a = 0, float b = 0, float c = 0, float d = 0) : x(a), y(b), z(c), w(d) {} float& operator[](int i) { return (&x)[i]; } const float& operator[](int i) const { return (&x)[i]; } };
+struct mat2 { float m[2][2]; float* operator[](int c) { return m[c]; } const float* operator[](int c) const { return m[c]; } };
+struct mat3 { float m[3][3]; float* operator[](int c) { return m[c]; } const float* operator[](int c) const { return m[c]; } };
 struct mat4 { float m[4][4]; float* operator[](int c) { return m[c]; } const float* operator[](int c) const { return m[c]; } };
+#endif
+static_assert(sizeof(vec3) == 12 && sizeof(vec4) == 16 && sizeof(mat4) == 64, "vectors and matrices are packed column-major floats");
 
 // ---- the "GL context": one gs4d context is current per thread (Application.cpp:97 glfwMakeContextCurrent) ----
 inline gs4d_ctx*& current_slot() { static thread_local gs4d_ctx* c = nullptr; return c; }
@@ -51,29 +70,52 @@ inline void Check(int rc, const char* what) {
 struct GLState {
     GLState() : handle(1, 0) {}
     std::vector<gs4d_buf> handle;            // GL name -> gs4d buffer (0 = no storage yet / deleted); name 0 is "none"
-    unsigned int bound_ssbo = 0;             // glBindBuffer(GL_SHADER_STORAGE_BUFFER, name)
+    unsigned int bound_ssbo = 0;             // glBindBuffer(target, name): one binding point is enough for what the scenes do
     gs4d_buf of(unsigned int name) const { return name < handle.size() ? handle[name] : 0; }
 };
 inline GLState& gl() { static thread_local GLState s; return s; }
 
 } } // namespace gs4d::compat
 
-// ---- the GL constants and the raw calls scenes make themselves -------------------------------------------------
-typedef unsigned int GLuint; typedef int GLint; typedef int GLsizei; typedef unsigned int GLenum; typedef float GLfloat; typedef std::ptrdiff_t GLsizeiptr; typedef std::ptrdiff_t GLintptr; typedef unsigned int GLbitfield;
+// ---- the GL types, constants and raw calls scenes make themselves ----------------------------------------------
+typedef unsigned int GLuint; typedef int GLint; typedef int GLsizei; typedef unsigned int GLenum; typedef float GLfloat; typedef std::ptrdiff_t GLsizeiptr; typedef std::ptrdiff_t GLintptr;
+typedef unsigned int GLbitfield; typedef unsigned char GLboolean; typedef void GLvoid;
 #ifndef GL_SHADER_STORAGE_BUFFER
 #define GL_SHADER_STORAGE_BUFFER 0x90D2
+#define GL_ARRAY_BUFFER 0x8892
+#define GL_ELEMENT_ARRAY_BUFFER 0x8893
 #define GL_DYNAMIC_STORAGE_BIT 0x0100
 #define GL_DYNAMIC_DRAW 0x88E8
+#define GL_STATIC_DRAW 0x88E4
 #define GL_FRAGMENT_SHADER 0x8B30
 #define GL_VERTEX_SHADER 0x8B31
+#define GL_COMPUTE_SHADER 0x91B9
 #define GL_SRC_ALPHA 0x0302
 #define GL_ONE_MINUS_SRC_ALPHA 0x0303
 #define GL_COLOR_BUFFER_BIT 0x4000
 #define GL_DEPTH_BUFFER_BIT 0x0100
+#define GL_BLEND 0x0BE2
+#define GL_DEPTH_TEST 0x0B71
+#define GL_FLOAT 0x1406
+#define GL_UNSIGNED_INT 0x1405
+#define GL_UNSIGNED_BYTE 0x1401
+#define GL_FALSE 0
+#define GL_TRUE 1
+#define GL_NO_ERROR 0
+#define GL_TRIANGLES 0x0004
+#define GL_LINES 0x0001
+#define GL_LINE_STRIP 0x0003
+#endif
+// Renderer.h:16-22: the error-check wrapper.  A failing call has already thrown (Check), so the wrapper only evaluates its argument.
+#ifndef ASSERT
+#define ASSERT(x) if (!(x)) throw std::runtime_error("ASSERT(" #x ")")
 #endif
 #ifndef GLCall
 #define GLCall(x) x
 #endif
+inline void GLClearError() {}
+inline bool GLLogCall(const char*, const char*, int) { return true; }
+inline GLenum glGetError() { return GL_NO_ERROR; }
 
 inline void glGenBuffers(GLsizei n, GLuint* names) { auto& g = gs4d::compat::gl(); for (GLsizei i = 0; i < n; ++i) { g.handle.push_back(0); names[i] = (GLuint)(g.handle.size() - 1); } }
 inline void glBindBuffer(GLenum, GLuint name) { gs4d::compat::gl().bound_ssbo = name; }
@@ -104,6 +146,10 @@ inline void glDeleteBuffers(GLsizei n, const GLuint* names) {   // deleting 0 / 
 inline void glClearColor(float r, float g, float b, float a) { const float c[4] = { r, g, b, a }; gs4d::compat::Check(gs4d_set_clear_color(gs4d::compat::Current(), c), "glClearColor"); }
 inline void glBlendFunc(GLenum s, GLenum d) { gs4d::compat::Check(gs4d_set_blend(gs4d::compat::Current(), (int)s, (int)d), "glBlendFunc"); }
 inline void glViewport(GLint, GLint, GLsizei w, GLsizei h) { gs4d::compat::Check(gs4d_resize(gs4d::compat::Current(), w, h), "glViewport"); }
+inline void glClear(GLbitfield) { gs4d::compat::Check(gs4d_clear(gs4d::compat::Current()), "glClear"); }
+inline void glEnable(GLenum) {}              // Application.cpp:153-163: blending is always on and the depth test always off on this path
+inline void glDisable(GLenum) {}
+inline void glLineWidth(GLfloat) {}          // the width travels with gs4d_draw_lines
 
 // ---- ShareStorageBuffer (ShareStorageBuffer.h:13-21) -------------------------------------------------------
 class ShareStorageBuffer {
@@ -129,57 +175,71 @@ private:
 
 // ---- Shader (Shader.h:28-72): the shader *paths* select the pipeline; uniforms go to the context -----------------
 typedef unsigned int ShaderType;
+struct ShaderSource { unsigned int type; std::string path; std::string source; };
 class Shader {
 public:
     Shader() {}
     Shader(Shader&) = delete;
-    void AddShaderSource(const std::string& path, ShaderType) {
+    void AddShaderSource(const std::string& path, ShaderType type) {
         // the pair of GLSL files a scene names identifies which fixed pipeline it wants
         if (path.find("Splat4DVertexShaderInstanced") != std::string::npos) m_mode = GS4D_MODE_4D_SORTED;
         else if (path.find("Splat4DVertexShaderMod") != std::string::npos) m_mode = GS4D_MODE_4D_DIRECT;
         else if (path.find("Splat3DVertexShaderFull") != std::string::npos) m_mode = GS4D_MODE_3D_FULL;
         else if (path.find("Splat2DVSI") != std::string::npos) m_mode = GS4D_MODE_2D;
-        m_paths.push_back(path);
+        else if (path.find("Shader/Lines/") != std::string::npos) m_lines = true;         // Renderer.h:29-34: drawn by gs4d_draw_lines
+        m_sources.push_back({ type, path, std::string() });
     }
-    void BuildShader() { if (m_mode < 0) std::fprintf(stderr, "[gs4d] Shader: no splat pipeline matches the given sources; draws with it are ignored\n"); }   // Shader.cpp:47-75 logs and continues
+    void BuildShader() { if (m_mode < 0 && !m_lines && !m_sources.empty()) std::fprintf(stderr, "[gs4d] Shader: no pipeline of this path matches %s; draws with it are ignored\n", m_sources.back().path.c_str()); }   // Shader.cpp:47-75 logs and continues
     void RebuildShader() { BuildShader(); }
     void Bind() const { if (m_mode >= 0) gs4d::compat::Check(gs4d_set_mode(gs4d::compat::Current(), m_mode), "Shader::Bind"); }
     void Unbind() const {}
     void SetUniform1f(const std::string& name, float v) {
+        if (m_mode < 0) return;
         if (name == "uTime") gs4d::compat::Check(gs4d_set_uniform_1f(gs4d::compat::Current(), GS4D_U_TIME, v), "SetUniform1f(uTime)");
         else if (name == "uMinOpacity") gs4d::compat::Check(gs4d_set_uniform_1f(gs4d::compat::Current(), GS4D_U_MIN_OPACITY, v), "SetUniform1f(uMinOpacity)");
     }
     template <class M> void SetUniformMat4f(const std::string& name, const M& m) {
         static_assert(sizeof(M) == 64, "SetUniformMat4f expects 16 column-major floats (glm::mat4)");
+        if (m_mode < 0) return;
         const float* p = reinterpret_cast<const float*>(&m);
         if (name == "uView") gs4d::compat::Check(gs4d_set_uniform_mat4(gs4d::compat::Current(), GS4D_U_VIEW, p), "SetUniformMat4f(uView)");
         else if (name == "uProj") gs4d::compat::Check(gs4d_set_uniform_mat4(gs4d::compat::Current(), GS4D_U_PROJ, p), "SetUniformMat4f(uProj)");
     }
-    // uniforms of other arities exist in the reference for the legacy per-splat shaders; accepted and ignored
+    // uniforms of other arities exist in the reference for the legacy per-splat shaders (Splat.h:163-247, 355-431, 584-600); accepted and ignored
     void SetUniform1i(const std::string&, int) {}
     void SetUniform2f(const std::string&, float, float) {}
     void SetUniform3f(const std::string&, float, float, float) {}
     void SetUniform4f(const std::string&, float, float, float, float) {}
-    template <class V> void SetUniform2f(const std::string&, const V&) {}         // glm::vec2 / vec3 / vec4 overloads (Shader.h:47-59)
-    template <class V> void SetUniform3f(const std::string&, const V&) {}
-    template <class V> void SetUniform4f(const std::string&, const V&) {}
-    template <class M> void SetUniformMat3f(const std::string&, const M&) {}     // Shader.h:64-68
-    template <class M> void SetUniformMat2f(const std::string&, const M&) {}
-    static bool TryCompile(const std::string&, ShaderType) { return true; }      // no GLSL is compiled on this path
+    void SetUniform2f(const std::string&, gs4d::compat::vec2) {}                  // Shader.h:47-59
+    void SetUniform3f(const std::string&, gs4d::compat::vec3) {}
+    void SetUniform4f(const std::string&, gs4d::compat::vec4) {}
+    void SetUniformMat3f(const std::string&, gs4d::compat::mat3) {}               // Shader.h:64-68
+    void SetUniformMat2f(const std::string&, gs4d::compat::mat2) {}
+    static bool TryCompile(std::string, ShaderType) { return true; }               // no GLSL is compiled on this path
+    void DispatchCompute(unsigned int, unsigned int, unsigned int) {}
+    void DispatchCompute(unsigned int, unsigned int) {}
+    unsigned int GetRenderID() { return 0; }
+    size_t GetShaderID() { return 0; }
+    std::vector<ShaderSource> GetShaderSources() { return m_sources; }
+    ShaderSource* GetShourceByIdx(int idx) { return idx >= 0 && (size_t)idx < m_sources.size() ? &m_sources[idx] : nullptr; }
+    size_t GetShaderSourceSize() { return m_sources.size(); }
     int Mode() const { return m_mode; }
 private:
     int m_mode = -1;
-    std::vector<std::string> m_paths;
+    bool m_lines = false;
+    std::vector<ShaderSource> m_sources;
 };
 
 // ---- vertex-side wrappers: API shape only (the unit quad of Geometry.h:44-50 is built into the rasteriser) -----
 class VertexBuffer {
 public:
-    VertexBuffer(const void* data, unsigned int size) { glGenBuffers(1, &m_id); glBindBuffer(GL_SHADER_STORAGE_BUFFER, m_id); glBufferData(GL_SHADER_STORAGE_BUFFER, size, data, GL_DYNAMIC_DRAW); }
+    VertexBuffer(const void* data, unsigned int size) { glGenBuffers(1, &m_id); glBindBuffer(GL_ARRAY_BUFFER, m_id); glBufferData(GL_ARRAY_BUFFER, size, data, GL_DYNAMIC_DRAW); }
     ~VertexBuffer() { glDeleteBuffers(1, &m_id); }
     VertexBuffer(const VertexBuffer&) = delete;
     void Bind() const {} void Unbind() const {}
-    void SubData(unsigned int offset, const void* data, unsigned int size) const { glBindBuffer(GL_SHADER_STORAGE_BUFFER, m_id); glBufferSubData(GL_SHADER_STORAGE_BUFFER, offset, size, data); }
+    void SubData(unsigned int offset, const void* data, unsigned int size) const { glBindBuffer(GL_ARRAY_BUFFER, m_id); glBufferSubData(GL_ARRAY_BUFFER, offset, size, data); }
+    void SubData(const void* data, unsigned int size) const { SubData(0, data, size); }
+    bool isDynamic() { return true; }
     unsigned int Name() const { return m_id; }
 private:
     unsigned int m_id = 0;
@@ -189,10 +249,18 @@ public:
     IndexBuffer(const unsigned int*, unsigned int count) : m_Count(count) {}
     void Bind() const {} void Unbind() const {}
     unsigned int GetCount() const { return m_Count; }
+    void SubData(unsigned int, const void*, unsigned int) const {}
 private:
     unsigned int m_Count;
 };
-class VertexBufferLayout { public: template <class T> void Push(unsigned int = 1) {} };
+struct VertexBufferElement { unsigned int type, count, normalized; unsigned int customOffset = 0; bool useCustomOffset = false;
+    static unsigned int GetSizeOfType(unsigned int type) { return type == GL_UNSIGNED_BYTE ? 1u : 4u; } };
+class VertexBufferLayout {                                                         // VertexBufferLayout.h:39-128: the layout is fixed by the pipeline mode here
+public:
+    template <class T> void Push(unsigned int) {}
+    template <class T> void Push() {}
+    unsigned int GetStride() const { return 0; }
+};
 class VertexArray {
 public:
     void AddBuffer(const VertexBuffer& vb, const VertexBufferLayout&) { m_vb = vb.Name(); }
@@ -201,26 +269,188 @@ public:
 private:
     unsigned int m_vb = 0;
 };
-namespace Geometry {
-struct Vertex2D { float Position[2]; };
+namespace Geometry {                                                              // Geometry.h:18-68
+struct Vertex { gs4d::compat::vec2 Position; gs4d::compat::vec4 Color; };
+struct Vertex2D { gs4d::compat::vec2 Position; };
+struct Splat4DVertex { gs4d::compat::vec2 VPosition; gs4d::compat::vec4 SPosition; gs4d::compat::vec4 Color; gs4d::compat::mat4 GeoInfo; };
+struct Splat3DVertex { gs4d::compat::vec2 VPosition; gs4d::compat::vec3 SPosition; gs4d::compat::vec4 Color; gs4d::compat::mat3 GeoInfo; };
+static_assert(sizeof(Splat3DVertex) == 72, "the 72-byte vertex gs4d_draw_quads takes (Geometry.h:37-42)");
+const Vertex2D QuadVerteices[] = { { { 0.5f, 0.5f } }, { { 0.5f, -0.5f } }, { { -0.5f, -0.5f } }, { { -0.5f, 0.5f } } };
+const unsigned int QuadIdxBufferData[] = { 0, 2, 1, 2, 0, 3 };
 struct Quad {
-    const Vertex2D QuadVerteices[4] = { { { 0.5f, 0.5f } }, { { 0.5f, -0.5f } }, { { -0.5f, -0.5f } }, { { -0.5f, 0.5f } } };
-    const unsigned int QuadIdxBufferData[6] = { 0, 2, 1, 2, 0, 3 };
-    VertexBuffer QuadVB{ QuadVerteices, sizeof QuadVerteices };
+    VertexBuffer QuadVB{ QuadVerteices, 4 * sizeof(Vertex2D) };
     IndexBuffer QuadIdxBuffer{ QuadIdxBufferData, 6 };
     VertexArray QuadVA{};
     VertexBufferLayout QuadVBLayout{};
-    Quad() { QuadVA.AddBuffer(QuadVB, QuadVBLayout); }
+    Quad() { QuadVBLayout.Push<gs4d::compat::vec2>(); QuadVA.AddBuffer(QuadVB, QuadVBLayout); }
+    ~Quad() {}
 };
 }
 
-// ---- Renderer (Renderer.h:37-39) -----------------------------------------------------------------------------
+// ---- input model behind the GLFW calls the reference makes (host/shadow/GLFW/glfw3.h): a window is just its input state -------
+struct GLFWwindow {
+    unsigned char keys[512] = { 0 };         // indexed by GLFW key code: 1 = pressed
+    double cursor_x = 0.0, cursor_y = 0.0;
+    int cursor_mode = 0;
+    bool should_close = false;
+};
+#ifndef GLFW_PRESS
+#define GLFW_RELEASE 0
+#define GLFW_PRESS 1
+#define GLFW_KEY_SPACE 32
+#define GLFW_KEY_A 65
+#define GLFW_KEY_C 67
+#define GLFW_KEY_D 68
+#define GLFW_KEY_E 69
+#define GLFW_KEY_M 77
+#define GLFW_KEY_Q 81
+#define GLFW_KEY_S 83
+#define GLFW_KEY_W 87
+#define GLFW_KEY_ESCAPE 256
+#define GLFW_KEY_LEFT_SHIFT 340
+#define GLFW_KEY_LEFT_CONTROL 341
+#define GLFW_CURSOR 0x00033001
+#define GLFW_CURSOR_NORMAL 0x00034001
+#define GLFW_CURSOR_HIDDEN 0x00034002
+inline int glfwGetKey(GLFWwindow* w, int key) { return (w && key >= 0 && key < 512 && w->keys[key]) ? GLFW_PRESS : GLFW_RELEASE; }
+inline void glfwSetInputMode(GLFWwindow* w, int mode, int value) { if (w && mode == GLFW_CURSOR) w->cursor_mode = value; }
+inline void glfwSetCursorPos(GLFWwindow* w, double x, double y) { if (w) { w->cursor_x = x; w->cursor_y = y; } }
+inline void glfwGetCursorPos(GLFWwindow* w, double* x, double* y) { if (x) *x = w ? w->cursor_x : 0.0; if (y) *y = w ? w->cursor_y : 0.0; }
+inline int glfwWindowShouldClose(GLFWwindow* w) { return w ? (int)w->should_close : 1; }
+inline void glfwPollEvents() {}
+#endif
+
+// ---- Camera (Camera.h:16-85, Camera.cpp) ---------------------------------------------------------------------------
+class Camera {
+public:
+    gs4d::compat::vec3 position, orientation{ 1.0f, 0.0f, 0.0f }, up{ 0.0f, 1.0f, 0.0f };
+    Camera(int width, int height) : position(0.0f, 0.0f, 0.0f), orientation(0.0f, 0.0f, -1.0f), mWidth(width), mHeight(height) {}
+    Camera(int width, int height, gs4d::compat::vec3 startPos) : position(startPos), orientation(0.0f, 0.0f, -1.0f), mWidth(width), mHeight(height) {}
+    Camera(int width, int height, gs4d::compat::vec3 startPos, gs4d::compat::vec3 o) : position(startPos), orientation(o), mWidth(width), mHeight(height) {}
+    Camera(int width, int height, gs4d::compat::vec3 startPos, gs4d::compat::vec3 o, gs4d::compat::vec3 u) : position(startPos), orientation(o), up(u), mWidth(width), mHeight(height) {}
+    gs4d::compat::mat4 GetViewMatrix() { gs4d::compat::mat4 m; gs4d_host_look_at(&position[0], &orientation[0], &up[0], reinterpret_cast<float*>(&m)); return m; }      // Camera.cpp:50-53
+    gs4d::compat::mat4 GetProjMatrix() { gs4d::compat::mat4 m; gs4d_host_perspective(mFOV, mWidth, mHeight, mNear, mFar, reinterpret_cast<float*>(&m)); return m; }   // Camera.cpp:55-58
+    // glm::mat4 operator*: Result[c] = sum_k A[k] * B[c][k], summed left to right (type_mat4x4.inl), A = proj, B = view (Camera.cpp:44-48)
+    gs4d::compat::mat4 GetViewProjMatrix() {
+        gs4d::compat::mat4 P = GetProjMatrix(), V = GetViewMatrix(), R;
+        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) R[c][r] = ((P[0][r] * V[c][0] + P[1][r] * V[c][1]) + P[2][r] * V[c][2]) + P[3][r] * V[c][3];
+        return R;
+    }
+    gs4d::compat::vec3 GetPosition() { return position; }
+    float GetFar() { return mFar; } float GetNear() { return mNear; } float GetFOV() { return mFOV; }
+    float GetScreenWidth() { return (float)mWidth; } float GetScreenHeight() { return (float)mHeight; }
+    gs4d::compat::vec2 GetViewport() { float v[2]; gs4d_host_camera_viewport(mWidth, mHeight, v); return gs4d::compat::vec2(v[0], v[1]); }             // Camera.cpp:90-93
+    gs4d::compat::vec2 GetFocal() { float v[2]; gs4d_host_camera_focal(mFOV, mWidth, mHeight, v); return gs4d::compat::vec2(v[0], v[1]); }            // Camera.cpp:95-99
+    float GetSpeed() { return mSpeed; }
+    bool IsViewFixed() { return mFixViewPoint; }
+    bool IsPositionFixed() { return mFixPostion; }
+    // Camera.cpp:116-207: WASD / E,Q roll / space, ctrl / C captures the mouse, Esc releases it; the arithmetic is gs4d_host_camera_input
+    void HandleInput(GLFWwindow* window, bool imguiActive = false) {
+        gs4d_camera_state st = State();
+        gs4d_camera_input in; std::memset(&in, 0, sizeof in);
+        static const struct { int key; unsigned bit; } map[] = { { GLFW_KEY_W, GS4D_CAMKEY_W }, { GLFW_KEY_S, GS4D_CAMKEY_S }, { GLFW_KEY_A, GS4D_CAMKEY_A }, { GLFW_KEY_D, GS4D_CAMKEY_D },
+            { GLFW_KEY_E, GS4D_CAMKEY_E }, { GLFW_KEY_Q, GS4D_CAMKEY_Q }, { GLFW_KEY_SPACE, GS4D_CAMKEY_SPACE }, { GLFW_KEY_LEFT_CONTROL, GS4D_CAMKEY_LCTRL }, { GLFW_KEY_LEFT_SHIFT, GS4D_CAMKEY_LSHIFT },
+            { GLFW_KEY_C, GS4D_CAMKEY_C }, { GLFW_KEY_ESCAPE, GS4D_CAMKEY_ESC } };
+        for (const auto& m : map) if (glfwGetKey(window, m.key) == GLFW_PRESS) in.keys |= m.bit;
+        glfwGetCursorPos(window, &in.mouse_x, &in.mouse_y);
+        in.imgui_active = imguiActive ? 1 : 0;
+        int recenter = 0, hide = 0;
+        gs4d_host_camera_input(&st, &in, &recenter, &hide);
+        if (hide) glfwSetInputMode(window, GLFW_CURSOR, GLFW_CURSOR_HIDDEN);
+        if (recenter) glfwSetCursorPos(window, (double)mWidth / 2.0, (double)mHeight / 2.0);
+        Load(st);
+    }
+    void HandleCamRotation(GLFWwindow* window) {                                   // Camera.cpp:191-207
+        gs4d_camera_state st = State();
+        double mx, my; glfwGetCursorPos(window, &mx, &my);
+        glfwSetCursorPos(window, (double)mWidth / 2.0, (double)mHeight / 2.0);
+        gs4d_host_camera_rotate(&st, mx, my);
+        Load(st);
+    }
+    void SetWidth(int width) { mWidth = width; } void SetHeight(int height) { mHeight = height; }
+    void SetNear(float v) { mNear = v; } void SetFar(float v) { mFar = v; } void SetFOV(float v) { mFOV = v; }
+    void Resize(int w, int h) { mWidth = w; mHeight = h; }
+    void SetPosition(gs4d::compat::vec3 p) { position = p; }
+    void SetOrientation(gs4d::compat::vec3 o) { orientation = o; }
+    void SetUp(gs4d::compat::vec3 u) { up = u; }
+    void SetIsViewFixedOnPoint(bool fixed, gs4d::compat::vec4 point) {            // Camera.cpp:209-220
+        SetIsViewFixedOnPoint(fixed);
+        if (fixed) { gs4d_camera_state st = State(); const float p[3] = { point[0], point[1], point[2] }; gs4d_host_camera_look_at_point(&st, p); Load(st); }
+    }
+    void SetIsViewFixedOnPoint(bool fixed) { mFixViewPoint = fixed; if (fixed) mCaptureMouse = false; }
+    void SetIsPositionFixed(bool fixed) { mFixPostion = fixed; }
+    void SetSpeed(float speed) { mSpeed = speed; }
+    bool IsLockX() { return mLockX; } bool IsLockY() { return mLockY; }
+    void SetLockX(bool lock) { mLockX = lock; } void SetLockY(bool lock) { mLockY = lock; }
+private:
+    gs4d_camera_state State() const {
+        gs4d_camera_state st;
+        for (int i = 0; i < 3; ++i) { st.position[i] = position[i]; st.orientation[i] = orientation[i]; st.up[i] = up[i]; }
+        st.width = mWidth; st.height = mHeight; st.sensitivity = mSensitivity; st.speed = mSpeed; st.fast_speed = mFastSpeed;
+        st.capture_mouse = mCaptureMouse; st.first_capture = mFirstCapture; st.fix_view = mFixViewPoint; st.fix_position = mFixPostion; st.lock_x = mLockX; st.lock_y = mLockY;
+        return st;
+    }
+    void Load(const gs4d_camera_state& st) {
+        for (int i = 0; i < 3; ++i) { position[i] = st.position[i]; orientation[i] = st.orientation[i]; up[i] = st.up[i]; }
+        mCaptureMouse = st.capture_mouse != 0; mFirstCapture = st.first_capture != 0;
+    }
+    bool mCaptureMouse = false, mFirstCapture = true, mFixViewPoint = false, mFixPostion = false;
+    float mFOV = 60.0f, mNear = 0.1f, mFar = 256.0f;      // Camera.h:71-73
+    int mWidth, mHeight;
+    float mSensitivity = 100.0f, mSpeed = 0.5f, mFastSpeed = 2.0f;
+    bool mLockY = false, mLockX = false;
+};
+
+// ---- Renderer (Renderer.h:24-50) -----------------------------------------------------------------------------
 class Renderer {
 public:
+    Renderer() {                                                                   // Renderer.h:28-35: the two line programs
+        mLine2D.AddShaderSource("../Shader/Lines/Line2DFrag.GLSL", GL_FRAGMENT_SHADER); mLine2D.AddShaderSource("../Shader/Lines/Line2DVert.GLSL", GL_VERTEX_SHADER); mLine2D.BuildShader();
+        mLine3D.AddShaderSource("../Shader/Lines/LineFrag.GLSL", GL_FRAGMENT_SHADER); mLine3D.AddShaderSource("../Shader/Lines/LineVert.GLSL", GL_VERTEX_SHADER); mLine3D.BuildShader();
+    }
     void Clear() const { gs4d::compat::Check(gs4d_clear(gs4d::compat::Current()), "Renderer::Clear"); }
     // non-instanced: the 3D-Full path, 4 vertices x 72 B per splat, 6 indices per splat (Scenes.h:1690-1692)
     void Draw(const VertexArray& va, const IndexBuffer& ib) const { gs4d::compat::Check(gs4d_draw_quads(gs4d::compat::Current(), gs4d::compat::gl().of(va.BoundVertexBuffer()), ib.GetCount() / 6), "Renderer::Draw"); }
     void Draw(const VertexArray&, const IndexBuffer&, int instances) const { gs4d::compat::Check(gs4d_draw_instanced(gs4d::compat::Current(), (size_t)instances), "Renderer::Draw(instanced)"); }
+    // overlays (Renderer.cpp:41-215): GL_LINES / GL_LINE_STRIP with the flat-colour programs of Shader/Lines, blended like everything else
+    void DrawLine(gs4d::compat::vec3 v0, gs4d::compat::vec3 v1, gs4d::compat::vec4 color, Camera& cam, float thickness) {
+        const float v[6] = { v0[0], v0[1], v0[2], v1[0], v1[1], v1[2] };
+        Lines(v, 2, 3, 0, cam, color, thickness, "Renderer::DrawLine");
+    }
+    void DrawLine(std::vector<gs4d::compat::vec3>& points, gs4d::compat::vec4 color, Camera& cam, float thickness) {
+        if (points.size() < 2) return;
+        Lines(reinterpret_cast<const float*>(points.data()), points.size(), 3, 1, cam, color, thickness, "Renderer::DrawLine(strip)");
+    }
+    void DrawLine(gs4d::compat::vec3 v0, gs4d::compat::vec3 v1, gs4d::compat::vec4 color, Camera& cam) { DrawLine(v0, v1, color, cam, 1.0f); }
+    void DrawGrid(float width, float height, const unsigned int divisionsX, const unsigned int divisionsY, gs4d::compat::vec4 color, Camera& cam, float thickness) {
+        // Renderer.cpp:113-135 sizes the vector to the line count and then push_back()s: the first `totalLines` vertices are (0,0,0) —
+        // degenerate segments that rasterise to nothing.  They are kept (the vertex count is part of the call) and cost nothing.
+        const int totalLines = (int)(((divisionsX + 1) * 2) + ((divisionsY + 1) * 2));
+        const float distX = width / divisionsX, distY = height / divisionsY;
+        std::vector<float> verts((size_t)totalLines * 3, 0.0f);
+        const float startX = -width / 2.0f, startY = -height / 2.0f;
+        for (int i = 0; i < (int)(divisionsX + 1); ++i) { const float x = startX + (distX * float(i)); verts.insert(verts.end(), { x, 0.0f, startY, x, 0.0f, -startY }); }
+        for (int i = 0; i < (int)(divisionsY + 1); ++i) { const float z = startY + (distY * float(i)); verts.insert(verts.end(), { startX, 0.0f, z, -startX, 0.0f, z }); }
+        Lines(verts.data(), verts.size() / 3, 3, 0, cam, color, thickness, "Renderer::DrawGrid");
+    }
+    void DrawLine(gs4d::compat::vec2 v0, gs4d::compat::vec2 v1, gs4d::compat::vec4 color) {                      // Renderer.cpp:170-203: NDC positions, width 3
+        const float v[4] = { v0[0], v0[1], v1[0], v1[1] };
+        const float c[4] = { color[0], color[1], color[2], color[3] };
+        gs4d::compat::Check(gs4d_draw_lines(gs4d::compat::Current(), v, 2, 2, 0, nullptr, c, 3.0f), "Renderer::DrawLine(2D)");
+    }
+    void DrawAxis(Camera& cam, float length = 1.0f, float thickness = 1.0f) {      // Renderer.cpp:205-215 (`length` is ignored there too: the axes are 10 long)
+        (void)length;
+        DrawLine(gs4d::compat::vec3(0.0f, 0.0f, 0.0f), gs4d::compat::vec3(10.0f, 0.0f, 0.0f), gs4d::compat::vec4(1.0f, 0.0f, 0.0f, 1.0f), cam, thickness);
+        DrawLine(gs4d::compat::vec3(0.0f, 0.0f, 0.0f), gs4d::compat::vec3(0.0f, 10.0f, 0.0f), gs4d::compat::vec4(0.0f, 1.0f, 0.0f, 1.0f), cam, thickness);
+        DrawLine(gs4d::compat::vec3(0.0f, 0.0f, 0.0f), gs4d::compat::vec3(0.0f, 0.0f, 10.0f), gs4d::compat::vec4(0.0f, 0.0f, 1.0f, 1.0f), cam, thickness);
+    }
+private:
+    void Lines(const float* v, size_t nverts, int dims, int strip, Camera& cam, const gs4d::compat::vec4& color, float thickness, const char* what) {
+        const gs4d::compat::mat4 vp = cam.GetViewProjMatrix();
+        const float c[4] = { color[0], color[1], color[2], color[3] };
+        gs4d::compat::Check(gs4d_draw_lines(gs4d::compat::Current(), v, nverts, dims, strip, reinterpret_cast<const float*>(&vp), c, thickness), what);
+    }
+    Shader mLine3D, mLine2D;
 };
 
 // ---- radix_sort::sorter (radix_sort.hpp:219, 258) ------------------------------------------------------------
@@ -230,32 +460,3 @@ struct sorter {
     void sort(GLuint key_buf, GLuint val_buf, size_t arr_len) { gs4d::compat::Check(gs4d_sort_pairs(gs4d::compat::Current(), gs4d::compat::gl().of(key_buf), gs4d::compat::gl().of(val_buf), arr_len), "radix_sort::sorter::sort"); }
 };
 }
-
-// ---- Camera (Camera.h:29-54): the three getters the path uses + the setters scenes call --------------------------
-class Camera {
-public:
-    gs4d::compat::vec3 position, orientation{ 1.0f, 0.0f, 0.0f }, up{ 0.0f, 1.0f, 0.0f };
-    Camera(int width, int height) : position(0, 0, 0), orientation(0, 0, -1), mWidth(width), mHeight(height) {}
-    template <class V> Camera(int width, int height, const V& p) : position(p[0], p[1], p[2]), orientation(0, 0, -1), mWidth(width), mHeight(height) {}
-    template <class V> Camera(int width, int height, const V& p, const V& o) : position(p[0], p[1], p[2]), orientation(o[0], o[1], o[2]), mWidth(width), mHeight(height) {}
-    gs4d::compat::mat4 GetViewMatrix() { gs4d::compat::mat4 m; gs4d_host_look_at(&position.x, &orientation.x, &up.x, &m.m[0][0]); return m; }
-    gs4d::compat::mat4 GetProjMatrix() { gs4d::compat::mat4 m; gs4d_host_perspective(mFOV, mWidth, mHeight, mNear, mFar, &m.m[0][0]); return m; }
-    // glm::mat4 operator*: Result[c] = sum_k A[k] * B[c][k], summed left to right (type_mat4x4.inl), A = proj, B = view (Camera.cpp:45-48)
-    gs4d::compat::mat4 GetViewProjMatrix() {
-        const gs4d::compat::mat4 P = GetProjMatrix(), V = GetViewMatrix(); gs4d::compat::mat4 R;
-        for (int c = 0; c < 4; ++c) for (int r = 0; r < 4; ++r) R.m[c][r] = ((P.m[0][r] * V.m[c][0] + P.m[1][r] * V.m[c][1]) + P.m[2][r] * V.m[c][2]) + P.m[3][r] * V.m[c][3];
-        return R;
-    }
-    gs4d::compat::vec3 GetPosition() { return position; }
-    float GetFar() { return mFar; } float GetNear() { return mNear; } float GetFOV() { return mFOV; }
-    float GetScreenWidth() { return (float)mWidth; } float GetScreenHeight() { return (float)mHeight; }
-    void SetNear(float v) { mNear = v; } void SetFar(float v) { mFar = v; } void SetFOV(float v) { mFOV = v; }
-    void SetWidth(int w) { mWidth = w; } void SetHeight(int h) { mHeight = h; }
-    void Resize(int w, int h) { mWidth = w; mHeight = h; }
-    template <class V> void SetPosition(const V& p) { position = gs4d::compat::vec3(p[0], p[1], p[2]); }
-    template <class V> void SetOrientation(const V& o) { orientation = gs4d::compat::vec3(o[0], o[1], o[2]); }
-    template <class V> void SetUp(const V& u) { up = gs4d::compat::vec3(u[0], u[1], u[2]); }
-private:
-    float mFOV = 60.0f, mNear = 0.1f, mFar = 256.0f;      // Camera.h:71-73
-    int mWidth, mHeight;
-};

@@ -119,6 +119,89 @@ void gs4d_host_perspective(float fov_deg, int width, int height, float znear, fl
     std::memcpy(proj, m, sizeof m);
 }
 
+// ---- Camera input model (Camera.cpp:90-99, 116-220) ----------------------------------------------------------------------
+static Vec3 v3(const float* p) { return { p[0], p[1], p[2] }; }
+static void put(float* p, Vec3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+static Vec3 add(Vec3 a, Vec3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+// glm::rotate(vec3 v, float angle, vec3 normal) = mat3(glm::rotate(mat4(1), angle, normal)) * v   (gtx/rotate_vector.inl:44-52,
+// ext/matrix_transform.inl:18-46; with m = identity the 4x4 product leaves Rotate itself)
+static Vec3 rotate_about(Vec3 v, float angle, Vec3 normal) {
+    const float c = std::cos(angle), s = std::sin(angle);
+    const Vec3 axis = unit(normal);
+    const Vec3 temp = scale(axis, 1.0f - c);
+    float R[3][3];
+    R[0][0] = c + temp.x * axis.x;          R[0][1] = temp.x * axis.y + s * axis.z; R[0][2] = temp.x * axis.z - s * axis.y;
+    R[1][0] = temp.y * axis.x - s * axis.z; R[1][1] = c + temp.y * axis.y;          R[1][2] = temp.y * axis.z + s * axis.x;
+    R[2][0] = temp.z * axis.x + s * axis.y; R[2][1] = temp.z * axis.y - s * axis.x; R[2][2] = c + temp.z * axis.z;
+    // Result[k] = m[0]*R[k][0] + m[1]*R[k][1] + m[2]*R[k][2] with m = identity: the products by 0 and 1 are exact, the sums add zeros
+    float M[3][3];
+    for (int k = 0; k < 3; ++k) for (int r = 0; r < 3; ++r) {
+        const float e0 = (r == 0 ? 1.0f : 0.0f) * R[k][0], e1 = (r == 1 ? 1.0f : 0.0f) * R[k][1], e2 = (r == 2 ? 1.0f : 0.0f) * R[k][2];
+        M[k][r] = e0 + e1 + e2;
+    }
+    return { M[0][0] * v.x + M[1][0] * v.y + M[2][0] * v.z, M[0][1] * v.x + M[1][1] * v.y + M[2][1] * v.z, M[0][2] * v.x + M[1][2] * v.y + M[2][2] * v.z };
+}
+
+void gs4d_host_camera_rotate(gs4d_camera_state* st, double mouseX, double mouseY) {
+    if (st->fix_view) return;
+    const double rotX = -(double)st->sensitivity * (mouseY - int((double)st->height / 2.0)) / (double)(st->height);
+    const double rotY = -(double)st->sensitivity * (mouseX - int((double)st->width / 2.0)) / (double)(st->width);
+    Vec3 o = v3(st->orientation), u = v3(st->up);
+    if (!st->lock_x) o = rotate_about(o, (float)(rotX * 0.01745329251994329576923690768489), unit(cross(o, u)));
+    const Vec3 side = unit(cross(u, o));
+    u = unit(cross(o, side));
+    if (!st->lock_y) o = rotate_about(o, (float)(rotY * 0.01745329251994329576923690768489), u);
+    put(st->orientation, o); put(st->up, u);
+}
+
+void gs4d_host_camera_input(gs4d_camera_state* st, const gs4d_camera_input* in, int* recenter_cursor, int* hide_cursor) {
+    if (recenter_cursor) *recenter_cursor = 0;
+    if (hide_cursor) *hide_cursor = 0;
+    if (in->imgui_active) return;
+    const float currentSpeed = (in->keys & GS4D_CAMKEY_LSHIFT) ? st->fast_speed : st->speed;
+    Vec3 p = v3(st->position), o = v3(st->orientation), u = v3(st->up);
+    if (!st->fix_position) {
+        if (in->keys & GS4D_CAMKEY_W) p = add(p, scale(o, currentSpeed));
+        if (in->keys & GS4D_CAMKEY_S) p = add(p, scale(o, -currentSpeed));
+        if (in->keys & GS4D_CAMKEY_A) { const Vec3 r = unit(cross(o, u)); const float k = -currentSpeed; p = add(p, { k * r.x, k * r.y, k * r.z }); }
+        if (in->keys & GS4D_CAMKEY_D) { const Vec3 r = unit(cross(o, u)); p = add(p, { currentSpeed * r.x, currentSpeed * r.y, currentSpeed * r.z }); }
+    }
+    if (in->keys & GS4D_CAMKEY_E) u = rotate_about(u, 1.0f * 0.01745329251994329576923690768489f, o);
+    if (in->keys & GS4D_CAMKEY_Q) u = rotate_about(u, -1.0f * 0.01745329251994329576923690768489f, o);
+    if (in->keys & GS4D_CAMKEY_SPACE) p = add(p, { currentSpeed * u.x, currentSpeed * u.y, currentSpeed * u.z });
+    if (in->keys & GS4D_CAMKEY_LCTRL) { const float k = -currentSpeed; p = add(p, { k * u.x, k * u.y, k * u.z }); }
+    put(st->position, p); put(st->up, u);
+    double mx = in->mouse_x, my = in->mouse_y;
+    if ((in->keys & GS4D_CAMKEY_C) && !st->capture_mouse) {
+        if (hide_cursor) *hide_cursor = 1;
+        if (recenter_cursor) *recenter_cursor = 1;
+        mx = (double)st->width / 2.0; my = (double)st->height / 2.0;
+        st->first_capture = 0; st->capture_mouse = 1;
+    }
+    if (in->keys & GS4D_CAMKEY_ESC) st->capture_mouse = 0;
+    if (st->capture_mouse) {
+        if (!st->fix_view && recenter_cursor) *recenter_cursor = 1;
+        gs4d_host_camera_rotate(st, mx, my);
+    }
+}
+
+void gs4d_host_camera_look_at_point(gs4d_camera_state* st, const float point[3]) {
+    const Vec3 o = unit(sub(v3(point), v3(st->position)));
+    const Vec3 side = unit(cross(v3(st->up), o));
+    put(st->orientation, o); put(st->up, unit(cross(o, side)));
+}
+
+void gs4d_host_camera_viewport(int width, int height, float out2[2]) {        // glm::normalize(glm::vec2(w, h)) = v * inversesqrt(dot(v, v))
+    const float x = (float)width, y = (float)height;
+    const float inv = 1.0f / std::sqrt(x * x + y * y);
+    out2[0] = x * inv; out2[1] = y * inv;
+}
+
+void gs4d_host_camera_focal(float fov, int width, int height, float out2[2]) { // the reference passes DEGREES to tanf (Camera.cpp:97): reproduced
+    const float d = (2.0f * tanf(fov * 0.5f));
+    out2[0] = width / d; out2[1] = height / d;
+}
+
 void gs4d_host_quat_look_at(const float dir[3], const float up[3], float q_wxyz[4]) {
     const Vec3 d = unit(Vec3{ dir[0], dir[1], dir[2] });
     const Vec3 back = { -d.x, -d.y, -d.z };

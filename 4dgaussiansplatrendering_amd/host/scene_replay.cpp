@@ -39,8 +39,7 @@ public:
     }
     ~LinearMotion() { if (m_key_buf) GLCall(glDeleteBuffers(1, &m_key_buf)); if (m_values_buf) GLCall(glDeleteBuffers(1, &m_values_buf)); }
     void init() {                                                                                                         // Scenes.h:226-289
-        const float p[3] = { 60, 90, 90 }, o[3] = { 0, -1.0f, -1.0f };
-        m_camera.SetPosition(p); m_camera.SetOrientation(o);
+        m_camera.SetPosition({ 60, 90, 90 }); m_camera.SetOrientation({ 0, -1.0f, -1.0f });
         const size_t nverts = m_vModelData.size() / 6;
         m_numOf4DSpltas = (unsigned)(nverts * m_steps_in_time);
         m_sdata.resize(m_numOf4DSpltas);

@@ -14,7 +14,7 @@ endif
 # keygen/sort and preprocess must round exactly like the CPU expressions they are checked against
 STRICT   := -ffp-contract=off
 
-OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(CSRC)/tilelist.o $(CSRC)/composite2.o $(HOST)/gs4d_host.o
+OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(CSRC)/tilelist.o $(CSRC)/composite2.o $(CSRC)/lines.o $(HOST)/gs4d_host.o
 
 .PHONY: all lib oracle ref clean demo
 all: lib oracle demo
@@ -27,6 +27,8 @@ lib: $(LIB)
 $(CSRC)/sort.o: $(CSRC)/sort.hip $(CSRC)/gs4d_internal.h include/gs4d.h
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
 $(CSRC)/preprocess.o: $(CSRC)/preprocess.hip $(CSRC)/gs4d_internal.h include/gs4d.h
+	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
+$(CSRC)/lines.o: $(CSRC)/lines.hip $(CSRC)/gs4d_internal.h include/gs4d.h
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/gs4d_internal.h $(CSRC)/composite_common.h include/gs4d.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -110,6 +110,14 @@ GS4D_API int gs4d_draw_instanced(gs4d_ctx* ctx, size_t instances);
 /* Renderer::Draw(va, ib) -> glDrawElements on 4 vertices x 72 B per splat (Scenes.h:1690-1692): GS4D_MODE_3D_FULL */
 GS4D_API int gs4d_draw_quads(gs4d_ctx* ctx, gs4d_buf vertices, size_t nquads);
 
+/* Overlay lines: Renderer::DrawLine / DrawGrid / DrawAxis (Renderer.cpp:41-215) with the flat-colour programs under Shader/Lines.
+ * nverts positions of `dims` floats each: dims == 3: gl_Position = viewproj * vec4(p, 1) (LineVert.GLSL:11); dims == 2: gl_Position =
+ * vec4(p, 0, 1), i.e. NDC (Line2DVert.GLSL:11; viewproj may be NULL).  strip == 0: GL_LINES (vertices 2k, 2k+1), else GL_LINE_STRIP.
+ * Segments are clipped to the view volume and rasterised as non-antialiased lines of `width` pixels (rounded, at least 1) — GL 4.4
+ * section 14.5.2 — and every fragment is blended into the current image with the context's blend function, after what was drawn
+ * before and before what is drawn next.  All fragments of one call carry the same colour. */
+GS4D_API int gs4d_draw_lines(gs4d_ctx* ctx, const float* verts, size_t nverts, int dims, int strip, const float viewproj[16], const float rgba[4], float width);
+
 /* ---- read-back (no reference counterpart: the reference never reads its framebuffer) ---- */
 GS4D_API int gs4d_read_pixels(gs4d_ctx* ctx, float* rgba, size_t bytes);          /* blocking; bytes == width*height*16     */
 GS4D_API int gs4d_read_pixels_device(gs4d_ctx* ctx, void* dptr, size_t bytes);    /* device-to-device, asynchronous: ordered into the caller's stream if one was given (gs4d_set_stream), else call gs4d_finish before using dptr */
@@ -184,6 +192,26 @@ GS4D_API void gs4d_host_scene_square(size_t nverts, const float* verts6, int ste
 GS4D_API long gs4d_host_parse_vdata(const char* path, float* verts6, size_t cap_vertices);                            /* VDataParser.h:25-58 */
 /* .sd splat files (23 numbers per splat) -> 96-byte records as ObjectDisplay::init builds them; returns the splat count or -1 */
 GS4D_API long gs4d_host_parse_sd(const char* path, float object_scale, float* records24, size_t cap_records);           /* VDataParser.h:60-123, Scenes.h:2483-2491 */
+
+/* Camera input model: Camera::HandleInput / HandleCamRotation / SetIsViewFixedOnPoint / GetViewport / GetFocal
+ * (Camera.cpp:90-99, 116-220) as a pure state machine — no window: the caller says which keys are down and where the cursor is. */
+enum { GS4D_CAMKEY_W = 1, GS4D_CAMKEY_S = 2, GS4D_CAMKEY_A = 4, GS4D_CAMKEY_D = 8, GS4D_CAMKEY_E = 16, GS4D_CAMKEY_Q = 32, GS4D_CAMKEY_SPACE = 64,
+       GS4D_CAMKEY_LCTRL = 128, GS4D_CAMKEY_LSHIFT = 256, GS4D_CAMKEY_C = 512, GS4D_CAMKEY_ESC = 1024 };
+typedef struct gs4d_camera_state {
+    float position[3], orientation[3], up[3];
+    int width, height;
+    float sensitivity, speed, fast_speed;                 /* Camera.h:78-80: 100, 0.5, 2 */
+    int capture_mouse, first_capture, fix_view, fix_position, lock_x, lock_y;
+} gs4d_camera_state;
+typedef struct gs4d_camera_input { unsigned keys; double mouse_x, mouse_y; int imgui_active; } gs4d_camera_input;
+/* One HandleInput call.  *recenter_cursor != 0: the reference moved the cursor to the window centre (glfwSetCursorPos) during the call;
+ * *hide_cursor != 0: it hid the cursor (glfwSetInputMode).  When C captures the mouse in this very call the rotation that follows reads
+ * the re-centred cursor, as the reference does. */
+GS4D_API void gs4d_host_camera_input(gs4d_camera_state* st, const gs4d_camera_input* in, int* recenter_cursor, int* hide_cursor);
+GS4D_API void gs4d_host_camera_rotate(gs4d_camera_state* st, double mouse_x, double mouse_y);            /* Camera.cpp:191-207 */
+GS4D_API void gs4d_host_camera_look_at_point(gs4d_camera_state* st, const float point[3]);              /* Camera.cpp:209-220 */
+GS4D_API void gs4d_host_camera_viewport(int width, int height, float out2[2]);                           /* Camera.cpp:90-93  */
+GS4D_API void gs4d_host_camera_focal(float fov, int width, int height, float out2[2]);                   /* Camera.cpp:95-99  */
 
 /* Presentation: an RGBA8 frame as produced by gs4d_read_pixels_rgba8_device (bottom row first) -> PNG file */
 GS4D_API int gs4d_host_write_png(const char* path, const uint8_t* rgba8, int width, int height);

@@ -588,6 +588,69 @@ GS4DO_API void gs4do_composite(const gs4do_proj* proj, const uint32_t* order, si
     for (auto& x : th) x.join();
 }
 
+// ---- overlay lines: Renderer::DrawLine / DrawGrid / DrawAxis (Renderer.cpp:41-215), Shader/Lines/LineVert.GLSL:11, Line2DVert.GLSL:11 ----
+// The vertex stage is the shader's (gl_Position = uViewProj * vec4(aPos, 1) resp. vec4(aPos, 0, 1)); clipping, line rasterisation and
+// the blend are fixed-function in the reference: restated from the OpenGL 4.4 core specification (13.5 clipping, 14.5.2.1 / 14.5.2.2
+// line segments and wide lines, 17.3.8 blending) in the form csrc/lines.hip documents.  PARITY UNPINNED: the reference holds no line
+// images.  Fragments are blended one after another, segment by segment — the order the GL would produce them in.
+static bool clip_t(float num, float den, float& t0, float& t1) {
+    if (den == 0.0f) return num >= 0.0f;
+    const float t = -num / den;
+    if (den > 0.0f) { if (t > t1) return false; if (t > t0) t0 = t; }
+    else { if (t < t0) return false; if (t < t1) t1 = t; }
+    return true;
+}
+GS4DO_API void gs4do_draw_lines(float* rgba, int W, int H, const float* verts, size_t nverts, int dims, int strip, const float* M, const float color[4], float width) {
+    const size_t nseg = strip ? (nverts >= 2 ? nverts - 1 : 0) : nverts / 2;
+    int wpx = (int)floorf(width + 0.5f); if (!(wpx >= 1)) wpx = 1; if (wpx > 64) wpx = 64;
+    const float a = color[3], om = 1.0f - a;
+    const float sr = color[0] * a, sg = color[1] * a, sb = color[2] * a, sa = a * a;
+    for (size_t s = 0; s < nseg; ++s) {
+        const size_t i0 = strip ? s : 2 * s, i1 = i0 + 1;
+        float c0[4], c1[4];
+        if (dims == 3) {
+            const float* p = verts + 3 * i0; const float* q = verts + 3 * i1;
+            for (int r = 0; r < 4; ++r) {
+                c0[r] = ((M[r] * p[0] + M[4 + r] * p[1]) + M[8 + r] * p[2]) + M[12 + r] * 1.0f;
+                c1[r] = ((M[r] * q[0] + M[4 + r] * q[1]) + M[8 + r] * q[2]) + M[12 + r] * 1.0f;
+            }
+        } else {
+            c0[0] = verts[2 * i0]; c0[1] = verts[2 * i0 + 1]; c0[2] = 0.0f; c0[3] = 1.0f;
+            c1[0] = verts[2 * i1]; c1[1] = verts[2 * i1 + 1]; c1[2] = 0.0f; c1[3] = 1.0f;
+        }
+        float t0 = 0.0f, t1 = 1.0f;
+        bool vis = true;
+        for (int ax = 0; ax < 3; ++ax) {
+            vis = vis && clip_t(c0[3] + c0[ax], (c1[3] - c0[3]) + (c1[ax] - c0[ax]), t0, t1);
+            vis = vis && clip_t(c0[3] - c0[ax], (c1[3] - c0[3]) - (c1[ax] - c0[ax]), t0, t1);
+        }
+        if (!vis || !(t0 <= t1)) continue;
+        float e0[4], e1[4];
+        for (int r = 0; r < 4; ++r) { const float d = c1[r] - c0[r]; e0[r] = c0[r] + t0 * d; e1[r] = c0[r] + t1 * d; }
+        if (!(e0[3] > 0.0f) || !(e1[3] > 0.0f)) continue;
+        const float hw = 0.5f * (float)W, hh = 0.5f * (float)H;
+        const float gax = (e0[0] / e0[3] + 1.0f) * hw, gay = (e0[1] / e0[3] + 1.0f) * hh;
+        const float gbx = (e1[0] / e1[3] + 1.0f) * hw, gby = (e1[1] / e1[3] + 1.0f) * hh;
+        if (!(std::isfinite(gax) && std::isfinite(gay) && std::isfinite(gbx) && std::isfinite(gby))) continue;
+        const bool xmajor = fabsf(gbx - gax) >= fabsf(gby - gay);
+        float ma = xmajor ? gax : gay, mb = xmajor ? gbx : gby, na = xmajor ? gay : gax, nb = xmajor ? gby : gbx;
+        if (ma > mb) { std::swap(ma, mb); std::swap(na, nb); }
+        if (!(mb > ma)) continue;
+        const float first = ceilf(ma - 0.5f), last = ceilf(mb - 0.5f);
+        for (float i = first; i < last; i += 1.0f) {
+            const float t = ((i + 0.5f) - ma) / (mb - ma);
+            const float minor = (na + t * (nb - na)) - 0.5f * (float)(wpx - 1);
+            for (int k = 0; k < wpx; ++k) {
+                const float j = floorf(minor) + (float)k;
+                const float x = xmajor ? i : j, y = xmajor ? j : i;
+                if (!(x >= 0.0f && y >= 0.0f && x < (float)W && y < (float)H)) continue;
+                float* d = rgba + 4 * ((size_t)(int)y * W + (int)x);
+                d[0] = sr + d[0] * om; d[1] = sg + d[1] * om; d[2] = sb + d[2] * om; d[3] = sa + d[3] * om;
+            }
+        }
+    }
+}
+
 GS4DO_API void gs4do_clear(float* rgba, int W, int H, const float clear[4]) {
     for (size_t i = 0; i < (size_t)W * H; ++i) { rgba[4 * i] = clear[0]; rgba[4 * i + 1] = clear[1]; rgba[4 * i + 2] = clear[2]; rgba[4 * i + 3] = clear[3]; }
 }

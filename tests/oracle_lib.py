@@ -159,6 +159,16 @@ def composite(proj_arr, order, frag_mode, W, H, rgba, nthreads=8):
     return rgba
 
 
+def draw_lines(rgba, verts, color, width=1.0, viewproj=None, strip=False):
+    """Overlay lines blended into `rgba` (H, W, 4) in place; verts (n, 3) with viewproj or (n, 2) NDC."""
+    H, W = rgba.shape[:2]
+    v = _f32(verts)
+    dims = v.shape[-1]
+    vp = _f32(viewproj) if viewproj is not None else np.eye(4, dtype=np.float32).reshape(-1)
+    lib().gs4do_draw_lines(_p(rgba), C.c_int(W), C.c_int(H), _p(v), C.c_size_t(v.size // dims), C.c_int(dims), C.c_int(1 if strip else 0), _p(vp), _p(_f32(color)), C.c_float(width))
+    return rgba
+
+
 CLEAR = np.array([0.18431373, 0.20784314, 0.25882353, 1.0], np.float32)  # Application.cpp:125
 
 

@@ -272,3 +272,62 @@ def test_caller_stream_handoff_with_refilled_device_buffer(gs4d, oracle, monkeyp
     assert linf(outsf[0].numpy(), outsf[1].numpy()) > 0.05           # the three frames do differ: stale records would be noticed
     ctx.set_stream(None)
     ctx.close()
+
+
+def _grid_vertices(width, height, dx, dy):
+    """The vertex array Renderer::DrawGrid builds (Renderer.cpp:113-135), including its zero-initialised first half."""
+    total = (dx + 1) * 2 + (dy + 1) * 2
+    v = [np.zeros((total, 3), np.float32)]
+    sx, sy = -width / 2.0, -height / 2.0
+    for i in range(dx + 1):
+        x = np.float32(sx) + np.float32(width / dx) * np.float32(i)
+        v.append(np.array([[x, 0, sy], [x, 0, -sy]], np.float32))
+    for i in range(dy + 1):
+        z = np.float32(sy) + np.float32(height / dy) * np.float32(i)
+        v.append(np.array([[sx, 0, z], [-sx, 0, z]], np.float32))
+    return np.concatenate(v)
+
+
+def test_overlay_lines_then_splats(gs4d, oracle, monkeypatch):
+    """What every 4D scene's Render() starts with (Scenes.h:303-310): grid, axes, a path — then the splats over them.  The line
+    rasterisation rule is the build's (GL leaves it to the implementation; csrc/lines.hip states it): parity unpinned, GPU == checker."""
+    W, H = 1280, 720
+    ctx = _ctx(gs4d, W, H, monkeypatch)
+    cam = scenes.CAM_TEAPOT
+    view, proj = cam_mats(gs4d, cam, W, H)
+    vp = (proj.reshape(4, 4).T @ view.reshape(4, 4).T).T.reshape(-1).astype(np.float32)        # column-major P * V
+    rec = oracle.golden("linear_first1000")
+    grid = _grid_vertices(2000.0, 2000.0, 200, 200)
+    axes = [(np.array([[0, 0, 0], [10, 0, 0]], np.float32), (1, 0, 0, 1)), (np.array([[0, 0, 0], [0, 10, 0]], np.float32), (0, 1, 0, 1)),
+            (np.array([[0, 0, 0], [0, 0, 10]], np.float32), (0, 0, 1, 1))]
+    path = np.stack([np.array([20 * np.cos(a), 5.0 + a, 20 * np.sin(a)], np.float32) for a in np.linspace(0, 6.0, 60)])
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.clear()
+    eimg = oracle.clear_image(W, H)
+    for verts, col, width, kw in [(grid, (1, 1, 1, 0.15), 1.0, {}), *[(v, c, 3.0, {}) for v, c in axes], (path, (1.0, 0.5, 0.1, 0.8), 5.0, {"strip": True})]:
+        ctx.draw_lines(verts, col, width, viewproj=vp, **kw)
+        oracle.draw_lines(eimg, verts, col, width, viewproj=vp, **kw)
+    seg2d = np.array([[-0.9, -0.8], [0.7, 0.95]], np.float32)
+    ctx.draw_lines(seg2d, (0.2, 0.9, 0.3, 0.5), 3.0)
+    oracle.draw_lines(eimg, seg2d, (0.2, 0.9, 0.3, 0.5), 3.0)
+    lines_only = ctx.read_pixels()
+    assert np.abs(eimg - oracle.clear_image(W, H)).max() > 0.3          # lines are there
+    diff = np.abs(lines_only.astype(np.float64) - eimg).max(axis=2)
+    assert (diff > 1e-6).mean() < 1e-5 and diff.max() <= TOL
+    # the splats of the frame blend over the overlays
+    n = rec.shape[0]
+    db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+    ctx.keygen(db, 0.0, cam[0], kb, ib, n)
+    ctx.sort_pairs(kb, ib, n)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.bind(1, ib)
+    ctx.bind(2, db)
+    ctx.draw_instanced(n)
+    img = ctx.read_pixels()
+    eidx, ekeys = oracle.keygen(rec, 0.0, cam[0])
+    _, eperm = oracle.sort_pairs(ekeys.view(np.uint32), eidx, "std")
+    oracle.composite(oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, 0.0, 0.0), eperm, oracle.MODE_4D, W, H, eimg)
+    diff = np.abs(img.astype(np.float64) - eimg).max(axis=2)
+    assert (diff > 1e-5).mean() < 1e-5 and diff.max() <= TOL
+    ctx.close()
