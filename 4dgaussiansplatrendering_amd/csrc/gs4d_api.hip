@@ -302,8 +302,8 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
     uint2* entries = tmp + L.pair_cap;
     {
         StageTimer t(c, GS4D_T_BINNING);
-        HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
-        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, tmp, c->tiles_x, c->shard_rank, c->shard_world));
+        HIPCHK(c, launch_bucket_scan(L.s, L.tl));
+        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, L.host_total_dev, L.pair_cap, tmp, c->tiles_x, c->shard_rank, c->shard_world));
         HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, L.host_total_dev, tmp, entries, c->list_hint));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event
@@ -371,7 +371,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             StageTimer t(c, GS4D_T_PREPROCESS);
             const PreOut po = { L.proj, L.rects };
             TileCount tc;
-            if (v2) { tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.tiles_x = c->tiles_x; tc.shard_rank = c->shard_rank; tc.shard_world = c->shard_world; tc.ks = a.ks; }
+            if (v2) { tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.rows = L.tl.rows; tc.tiles_x = c->tiles_x; tc.shard_rank = c->shard_rank; tc.shard_world = c->shard_world; tc.ks = a.ks; }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, npre, a.u, c->W, c->H, po, tc));

@@ -105,7 +105,8 @@ struct KeySrc {
     uint32_t bias = 0;                           // subtracted from the key's bit pattern (host-proven lower bound, as in the depth sort)
 };
 struct TileCount {                               // hist == nullptr: the ordered path (no counting in the projection kernel)
-    uint32_t* hist = nullptr;                    // [rows][nb]: entries that the records of segment `row` put into bucket b = tile % nb
+    uint32_t* hist = nullptr;                    // [nb][rows]: entries that the records of segment `row` put into bucket b = tile % nb
+    uint32_t rows = 0;
     uint32_t* skey = nullptr;                    // [records] blend-order key of every record
     uint32_t nb = 0, seg = 0;                    // buckets (a power of two), records per segment (a multiple of 256; one workgroup walks one segment)
     int tiles_x = 0, shard_rank = 0, shard_world = 1;
@@ -114,8 +115,8 @@ struct TileCount {                               // hist == nullptr: the ordered
 constexpr uint32_t V2_MAX_LIST = 2048;           // longest per-tile list the compositor sorts in LDS; beyond it a draw uses the ordered path
 constexpr uint32_t V2_MAX_RECORDS = 1u << 24;    // an entry carries (tile / nb) in the top byte of its record word
 struct TileLists {
-    uint32_t* hist = nullptr; size_t hist_cap = 0;            // [rows][nb] counts, turned in place into the first entry slot of every (segment, bucket) run
-    uint32_t* bbase = nullptr; uint32_t* tstart = nullptr; uint32_t* tcnt = nullptr; size_t tiles_cap = 0, nb_cap = 0;   // [nb + 1] bucket starts; per tile: first entry, entries
+    uint32_t* hist = nullptr; size_t hist_cap = 0;            // [nb][rows] counts, turned in place into the slot of every (segment, bucket) run inside its bucket
+    uint32_t* bbase = nullptr; uint32_t* btot = nullptr; uint32_t* tstart = nullptr; uint32_t* tcnt = nullptr; size_t tiles_cap = 0, nb_cap = 0;   // [nb + 1] bucket starts, [nb] bucket totals; per tile: first entry, entries
     uint32_t* skey = nullptr; size_t skey_cap = 0;
     uint32_t nb = 0, rows = 0, seg = 0;                       // geometry of the current draw (tile_lists_plan)
 };
@@ -125,8 +126,8 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
 void tile_lists_free(TileLists& t);
 // total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list,
 // [6] workgroups of k_bucket_tiles that have finished; total_host (pinned, mapped) receives [0..3] and the longest list at [5]
-hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap);
-hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
+hipError_t launch_bucket_scan(hipStream_t st, TileLists& t);
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, uint32_t* total, uint32_t* total_host, size_t cap, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, const uint2* tmp, uint2* entries, uint32_t hint);
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits);

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_preprocess(SRC src, uint32_t n, PU u, P
         count_buckets(h, tc.nb - 1u, (uint32_t)tc.tiles_x, r);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < tc.nb; b += 256u) tc.hist[(size_t)blockIdx.x * tc.nb + b] = h[b];
+    for (uint32_t b = threadIdx.x; b < tc.nb; b += 256u) tc.hist[(size_t)b * tc.rows + blockIdx.x] = h[b];       // one row per bucket: k_bucket_scan scans along the segments
 }
 
 static PU make_pu(const Uniforms& un, int W, int H) {

@@ -10,9 +10,10 @@
 //   bucket b = tile % nb   (interleaved: the dense image centre spreads over all buckets),   nb a power of two, tile / nb < 256
 //
 //   k_preprocess<.., true>  (preprocess.hip) walks segment w of the records (one workgroup, `seg` records) and leaves
-//                           hist[w][b] = entries its records put into bucket b            (LDS atomics, one plain row store)
-//   k_bucket_scan           column-wise exclusive scan: hist[w][b] becomes the first slot of run (w, b); bucket starts; capacity check
-//   k_bucket_scatter        walks the same segments again: entry -> tmp[run start + LDS counter]   (key, tile/nb << 24 | record)
+//                           hist[b][w] = entries its records put into bucket b            (LDS atomics, plain stores)
+//   k_bucket_scan           one wave per bucket: exclusive scan along w -> slot of run (w, b) inside bucket b; bucket totals
+//   k_bucket_scatter        walks the same segments again: entry -> tmp[bucket start + run slot + LDS counter]   (key, tile/nb << 24 | record);
+//                           bucket starts and the capacity check come from the bucket totals (every workgroup scans those 256..1024 numbers)
 //   k_bucket_tiles          one workgroup per bucket: counts its entries per tile in LDS, writes the tile table (first entry, count)
 //                           and moves the entries to their tile's list; the longest list is checked against the compositor's capacity
 //   k_composite_v2          (composite2.hip)
@@ -29,69 +30,72 @@ namespace gs4d {
 
 typedef unsigned long long u64;
 
-constexpr int SCAN_THREADS = 1024;
 
-// hist[w][b] (counts) -> first entry slot of run (w, b): runs of one bucket are laid out in segment order, buckets in index order.
-__global__ __launch_bounds__(SCAN_THREADS) void k_bucket_scan(uint32_t* __restrict__ hist, uint32_t rows, uint32_t nb, uint32_t* __restrict__ bbase,
-                                                              uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t cap) {
-    __shared__ u64 part[SCAN_THREADS];             // [row group][column]
-    __shared__ u64 wsum[SCAN_THREADS / 64];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t groups = SCAN_THREADS / nb;     // nb <= 1024
-    const uint32_t col = tid % nb, grp = tid / nb;
-    const uint32_t per = (rows + groups - 1u) / groups;
-    const uint32_t r0 = min(grp * per, rows), r1 = min(r0 + per, rows);
-    u64 sum = 0;
-    if (grp < groups) for (uint32_t r = r0; r < r1; ++r) sum += hist[(size_t)r * nb + col];
-    part[tid] = grp < groups ? sum : 0ull;
-    __syncthreads();
-    // column totals (threads 0..nb-1), exclusive scan over the columns
-    u64 colsum = 0;
-    if (tid < nb) for (uint32_t g = 0; g < groups; ++g) colsum += part[g * nb + tid];
-    u64 inc = tid < nb ? colsum : 0ull;
+// hist[b][w] (counts, one row per bucket) -> exclusive scan along w: the slot of run (w, b) inside bucket b; btot[b] = entries of bucket b.
+// One wave per bucket, 64 segments per step: every bucket is scanned in parallel (a single workgroup walking the whole matrix cost 100 us).
+__global__ __launch_bounds__(256) void k_bucket_scan(uint32_t* __restrict__ hist, uint32_t rows, uint32_t nb, uint32_t* __restrict__ btot) {
+    const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    uint32_t* __restrict__ h = hist + (size_t)b * rows;
+    uint32_t carry = 0;
+    for (uint32_t w0 = 0; w0 < rows; w0 += 64u) {
+        const uint32_t w = w0 + lane;
+        const uint32_t c = w < rows ? h[w] : 0u;
+        uint32_t inc = c;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const u64 v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
-    if (lane == 63u) wsum[w] = inc;
-    __syncthreads();
-    u64 base = 0, grand = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_THREADS / 64; ++k) { const u64 s = wsum[k]; if ((unsigned)k < w) base += s; grand += s; }
-    const u64 cstart = base + inc - colsum;        // first slot of bucket `tid`
-    __syncthreads();
-    if (tid < nb) {
-        bbase[tid] = cstart > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)cstart;
-        // first slot of every row group of this column (reusing part[])
-        u64 run = cstart;
-        for (uint32_t g = 0; g < groups; ++g) { const u64 c = part[g * nb + tid]; part[g * nb + tid] = run; run += c; }
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
+        if (w < rows) h[w] = carry + inc - c;
+        carry += __shfl(inc, 63, 64);
     }
-    __syncthreads();
-    if (grp < groups) {
-        u64 run = part[tid];
-        for (uint32_t r = r0; r < r1; ++r) {
-            const size_t o = (size_t)r * nb + col;
-            const uint32_t c = hist[o];
-            hist[o] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run;     // only meaningful when the draw is not aborted
-            run += c;
-        }
-    }
-    if (tid == 0) {
-        const uint32_t sat = grand > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)grand;
-        const uint32_t flags = grand > (u64)cap ? 1u : 0u;
-        bbase[nb] = sat;
-        total[0] = sat; total[1] = flags; total[2] = (uint32_t)grand; total[3] = (uint32_t)(grand >> 32); total[4] = 0u; total[6] = 0u;
-        // an aborted draw stops here: tell the host now (otherwise k_bucket_tiles reports, once the longest list is known)
-        if (flags) { total_host[0] = sat; total_host[1] = flags; total_host[2] = (uint32_t)grand; total_host[3] = (uint32_t)(grand >> 32); total_host[5] = 0u; }
-    }
+    if (lane == 0) btot[b] = carry;
 }
 
-// Segment w again: every entry goes to tmp[run start of (w, bucket) + a counter in LDS].  256 threads, one record each per round.
-__global__ __launch_bounds__(256) void k_bucket_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t n, uint32_t seg, uint32_t nb,
-                                                        const uint32_t* __restrict__ offs, const uint32_t* __restrict__ total, uint2* __restrict__ tmp,
+// exclusive scan of the bucket totals by a 256-thread workgroup (nb <= 1024): bucket starts into s_base[0..nb], returns the grand total
+__device__ __forceinline__ unsigned long long bucket_bases(const uint32_t* __restrict__ btot, uint32_t nb, uint32_t* s_base /* [1025] */, unsigned long long* s_ws /* [4] */) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    uint32_t v[4]; unsigned long long sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t b = tid * 4u + k; v[k] = b < nb ? btot[b] : 0u; sum += v[k]; }
+    unsigned long long inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const unsigned long long t = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += t; }
+    if (lane == 63u) s_ws[w] = inc;
+    __syncthreads();
+    unsigned long long base = 0, grand = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const unsigned long long t = s_ws[k]; if ((unsigned)k < w) base += t; grand += t; }
+    unsigned long long run = base + inc - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t b = tid * 4u + k; if (b < nb) s_base[b] = run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)run; run += v[k]; }
+    if (tid == 0) s_base[nb] = grand > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)grand;
+    __syncthreads();
+    return grand;
+}
+
+// Segment w again: every entry goes to tmp[bucket start + slot of run (w, bucket) + a counter in LDS].  256 threads, one record each per
+// round.  Every workgroup derives the bucket starts from the 256..1024 bucket totals itself; workgroup 0 also leaves them, the entry
+// count and the capacity verdict for the kernels and the host that come after.
+__global__ __launch_bounds__(256) void k_bucket_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t n, uint32_t seg, uint32_t nb, uint32_t rows,
+                                                        const uint32_t* __restrict__ hist, const uint32_t* __restrict__ btot, uint32_t* __restrict__ bbase,
+                                                        uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t cap, uint2* __restrict__ tmp,
                                                         uint32_t tiles_x, uint32_t shard_rank, uint32_t shard_world) {
-    __shared__ uint32_t cur[1024];
-    if (total[1] & 1u) return;                             // aborted draw: slots may lie beyond the capacity
+    __shared__ uint32_t cur[1025];
+    __shared__ unsigned long long s_ws[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    for (uint32_t b = tid; b < nb; b += 256u) cur[b] = offs[(size_t)blockIdx.x * nb + b];
+    const unsigned long long grand = bucket_bases(btot, nb, cur, s_ws);
+    const bool over = grand > (unsigned long long)cap;
+    if (blockIdx.x == 0) {
+        for (uint32_t b = tid; b <= nb; b += 256u) bbase[b] = cur[b];
+        if (tid == 0) {
+            const uint32_t sat = grand > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)grand;
+            total[0] = sat; total[1] = over ? 1u : 0u; total[2] = (uint32_t)grand; total[3] = (uint32_t)(grand >> 32); total[4] = 0u; total[6] = 0u;
+            // an aborted draw stops here: tell the host now (otherwise k_bucket_tiles reports, once the longest list is known)
+            if (over) { total_host[0] = sat; total_host[1] = 1u; total_host[2] = (uint32_t)grand; total_host[3] = (uint32_t)(grand >> 32); total_host[5] = 0u; }
+        }
+    }
+    if (over) return;                                      // uniform over the whole grid: slots would lie beyond the capacity
+    __syncthreads();
+    for (uint32_t b = tid; b < nb; b += 256u) cur[b] += hist[(size_t)b * rows + blockIdx.x];
     __syncthreads();
     const uint32_t nbm = nb - 1u, nbs = (uint32_t)__ffs((int)nb) - 1u;
     const uint32_t i0 = blockIdx.x * seg, i1 = min(n, i0 + seg);
@@ -200,10 +204,10 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
     }
     if (t.tiles_cap < ntiles || t.nb_cap < t.nb) {
         if (t.bbase) { (void)hipStreamSynchronize(st); (void)hipFree(t.bbase); }
-        t.bbase = t.tstart = t.tcnt = nullptr;
+        t.bbase = t.btot = t.tstart = t.tcnt = nullptr;
         const size_t nt = std::max(ntiles, t.tiles_cap), nbc = std::max<size_t>(t.nb, t.nb_cap);
-        if ((e = hipMalloc(&t.bbase, (nbc + 1 + 2 * nt) * 4)) != hipSuccess) return e;
-        t.tstart = t.bbase + nbc + 1; t.tcnt = t.tstart + nt;
+        if ((e = hipMalloc(&t.bbase, (2 * nbc + 1 + 2 * nt) * 4)) != hipSuccess) return e;
+        t.btot = t.bbase + nbc + 1; t.tstart = t.btot + nbc; t.tcnt = t.tstart + nt;
         t.tiles_cap = nt; t.nb_cap = nbc;
     }
     if (t.skey_cap < nrecords) {
@@ -222,13 +226,14 @@ void tile_lists_free(TileLists& t) {
     t = TileLists();
 }
 
-hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap) {
-    k_bucket_scan<<<dim3(1), dim3(SCAN_THREADS), 0, st>>>(t.hist, t.rows, t.nb, t.bbase, total, total_host, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFull));
+hipError_t launch_bucket_scan(hipStream_t st, TileLists& t) {
+    k_bucket_scan<<<dim3((t.nb + 3) / 4), dim3(256), 0, st>>>(t.hist, t.rows, t.nb, t.btot);
     return hipGetLastError();
 }
 
-hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
-    k_bucket_scatter<<<dim3(t.rows), dim3(256), 0, st>>>(rects, t.skey, (uint32_t)nrecords, t.seg, t.nb, t.hist, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, uint32_t* total, uint32_t* total_host, size_t cap, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
+    k_bucket_scatter<<<dim3(t.rows), dim3(256), 0, st>>>(rects, t.skey, (uint32_t)nrecords, t.seg, t.nb, t.rows, t.hist, t.btot, t.bbase, total, total_host,
+                                                         (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFull), tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
     return hipGetLastError();
 }
 

@@ -1,0 +1,4 @@
+// ShareStorageBuffer.h — replaces the reference's 4DSplatRendering/ShareStorageBuffer.h: the class(es) it declares are provided by gs4d_compat.h over libgs4d.so.
+// Copy this file over the reference's; everything that includes "ShareStorageBuffer.h" keeps compiling unchanged.
+#pragma once
+#include "gs4d_compat.h"

@@ -16,7 +16,7 @@ STRICT   := -ffp-contract=off
 
 OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(CSRC)/tilelist.o $(CSRC)/composite2.o $(CSRC)/lines.o $(HOST)/gs4d_host.o
 
-.PHONY: all lib oracle ref clean demo
+.PHONY: all lib oracle ref refscene clean demo
 all: lib oracle demo
 DEMO := $(HOST)/scene_replay
 demo: $(DEMO)
@@ -24,13 +24,13 @@ $(DEMO): $(HOST)/scene_replay.cpp $(HOST)/gs4d_compat.h include/gs4d.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -o $@ $(HOST)/scene_replay.cpp -L$(PKG) -lgs4d -Wl,-rpath,'$$ORIGIN/..'
 lib: $(LIB)
 
-$(CSRC)/sort.o: $(CSRC)/sort.hip $(CSRC)/gs4d_internal.h include/gs4d.h
+$(CSRC)/sort.o: $(CSRC)/sort.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
-$(CSRC)/preprocess.o: $(CSRC)/preprocess.hip $(CSRC)/gs4d_internal.h include/gs4d.h
+$(CSRC)/preprocess.o: $(CSRC)/preprocess.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
-$(CSRC)/lines.o: $(CSRC)/lines.hip $(CSRC)/gs4d_internal.h include/gs4d.h
+$(CSRC)/lines.o: $(CSRC)/lines.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/gs4d_internal.h $(CSRC)/composite_common.h include/gs4d.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/gs4d_internal.h $(CSRC)/composite_common.h include/gs4d.h Makefile
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(HOST)/gs4d_host.o: $(HOST)/gs4d_host.cpp include/gs4d.h
 	$(HIPCC) -O2 -std=c++17 -fPIC -fvisibility=hidden $(STRICT) -x c++ -c $< -o $@
@@ -42,6 +42,8 @@ oracle:
 	$(MAKE) -C oracle oracle
 ref:
 	$(MAKE) -C oracle ref
+refscene: lib
+	$(MAKE) -C oracle refscene
 
 clean:
 	rm -f $(OBJS) $(LIB) $(DEMO)

@@ -1,0 +1,68 @@
+"""GPU: the REFERENCE'S OWN scene classes on the HIP renderer.
+
+oracle/_ref/refscene is the reference's unmodified Scenes.h / Splat.h / Scene.h / Utils.cpp / VDataParser.h compiled against this
+repo's drop-in headers (4dgaussiansplatrendering_amd/host/shadow/) and linked with libgs4d.so — built in the development container
+where the reference tree exists (`make refscene`), shipped as a binary (oracle/_ref/ is git-ignored but travels to the GPU box).
+It runs Scenes::LinearMotion::init() / Update() / GUI() / Render() exactly as Application.cpp:145-182 would: teapot parse, Splat4D
+constructors with GLM, key loop on the CPU, glBufferSubData uploads, radix_sort::sorter::sort, uniforms, glBindBufferBase,
+Renderer::Draw, and the DrawGrid / DrawAxis / DrawLine overlays.  The frame must equal the CPU checker's picture of the same scene.
+Scene parameters the reference only exposes through its ImGui menu (sort on/off, time) are set through the scriptable ImGui stand-in.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_paths import _grid_vertices
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "oracle", "_ref", "refscene")
+
+
+def _viewproj(view, proj):
+    """Camera::GetViewProjMatrix = proj * view with glm's summation order (type_mat4x4.inl), in float32."""
+    P, V = proj.reshape(4, 4), view.reshape(4, 4)          # [column][row]
+    R = np.zeros((4, 4), np.float32)
+    for c in range(4):
+        for r in range(4):
+            R[c, r] = np.float32(np.float32(np.float32(P[0, r] * V[c, 0]) + np.float32(P[1, r] * V[c, 1])) + np.float32(P[2, r] * V[c, 2])) + np.float32(P[3, r] * V[c, 3])
+    return R.reshape(-1)
+
+
+@pytest.mark.skipif(not os.path.exists(EXE), reason="oracle/_ref/refscene is built only where the reference tree exists (make refscene)")
+@pytest.mark.parametrize("script,t,do_sort", [([], 0.0, False), (["Sort=1", "Time=12.5"], 12.5, True)])
+def test_reference_linear_motion_scene_drives_the_renderer(gs4d, oracle, tmp_path, script, t, do_sort):
+    W, H = 800, 800                                        # the reference's window (Application.cpp:59-60)
+    (tmp_path / "Objects").mkdir()
+    (tmp_path / "run").mkdir()
+    teapot = oracle.golden("teapot_vdata")
+    with open(tmp_path / "Objects" / "teapot.vdata", "w") as f:      # the asset the scene parses (Scenes.h:231), regenerated from the fixture
+        f.write(" ".join(repr(float(np.float32(x))) for x in teapot.reshape(-1)))
+    out = str(tmp_path / "frame.bin")
+    r = subprocess.run([EXE, "linear", out, str(W), str(H)] + script, cwd=str(tmp_path / "run"), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    img = np.fromfile(out, np.float32).reshape(H, W, 4)
+    # the same frame from the checker: overlays of Scenes.h:303-305, then the 182 200 splats
+    cam = scenes.CAM_TEAPOT
+    view = oracle.look_at(*cam)
+    proj = oracle.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
+    vp = _viewproj(view, proj)
+    eimg = oracle.clear_image(W, H)
+    oracle.draw_lines(eimg, _grid_vertices(2000.0, 2000.0, 200, 200), (1, 1, 1, 0.15), 1.0, viewproj=vp)
+    for end, col in (((10, 0, 0), (1, 0, 0, 1)), ((0, 10, 0), (0, 1, 0, 1)), ((0, 0, 10), (0, 0, 1, 1))):
+        oracle.draw_lines(eimg, np.array([(0, 0, 0), end], np.float32), col, 3.0, viewproj=vp)
+    oracle.draw_lines(eimg, np.array([(0, 0, 0), (1, 0, 0)], np.float32), (1, 1, 1, 1), 5.0, viewproj=vp)
+    assert np.abs(eimg - oracle.clear_image(W, H)).max() > 0.3
+    rec = gs4d.scene_linear(teapot)
+    eproj = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, 0.0)
+    order = None
+    if do_sort:
+        eidx, ekeys = oracle.keygen(rec, t, cam[0])
+        _, order = oracle.sort_pairs(ekeys.view(np.uint32), eidx, "std")
+    oracle.composite(eproj, order, oracle.MODE_4D, W, H, eimg, nthreads=16)
+    diff = np.abs(img.astype(np.float64) - eimg).max(axis=2)
+    assert (diff > 1e-5).mean() < 1e-5 and diff.max() <= 1e-4, (float(diff.max()), float((diff > 1e-5).mean()))
+    assert "camera 60 90 90" in r.stdout
