@@ -62,11 +62,14 @@ template <bool PREMULT_C, int PER>
 __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
                                                      const uint32_t* __restrict__ total, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
                                                      float4* __restrict__ fb, int key_passes, int rec_passes) {
-    __shared__ float4 stage[64 * 3];
+    // the sort's key plane and the blend's record staging never live at the same time: one piece of LDS serves both
+    constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
+    __shared__ __attribute__((aligned(16))) uint32_t sh_a[SHARED_WORDS];
     __shared__ uint32_t pmask[64 * 2];
     __shared__ uint32_t cnt[64];
-    __shared__ uint32_t ek[64 * PER];
     __shared__ uint32_t er[64 * PER];
+    float4* stage = reinterpret_cast<float4*>(sh_a);
+    uint32_t* ek = sh_a;
     if (total[1]) return;                                   // aborted draw (capacity or list length): the host re-runs it
     const uint32_t tile = blockIdx.x;
     const uint32_t lane = threadIdx.x;
@@ -126,9 +129,13 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
+    case 3: GS4D_V2(3); break;
     case 4: GS4D_V2(4); break;
+    case 6: GS4D_V2(6); break;
     case 8: GS4D_V2(8); break;
+    case 12: GS4D_V2(12); break;
     case 16: GS4D_V2(16); break;
+    case 24: GS4D_V2(24); break;
     default: GS4D_V2(32); break;
     }
 #undef GS4D_V2
@@ -138,7 +145,7 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits) {
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
-    int per = 1; while ((uint32_t)per * 64u < hint) per *= 2;
+    const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid((unsigned)(tiles_x * tiles_y));
     const int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;

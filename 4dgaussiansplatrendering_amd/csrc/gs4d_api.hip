@@ -120,6 +120,7 @@ struct gs4d_ctx {
     int path_pref = 0;                 // GS4D_DRAW_PATH: 0 auto, 1 ordered path only, 2 = auto (kept for symmetry)
     bool long_lists = false;           // the last unordered draw met a list longer than V2_MAX_LIST: draws use the ordered path ...
     uint64_t ordered_draws = 0;        // ... and probe the unordered one again every so often when the lists look short on average
+    int shrink_votes = 0;
     uint32_t list_hint = 256;          // LDS list capacity the compositor is launched with (64 << k); grows on demand, validated per draw on the device
     uint64_t stat_v2_draws = 0, stat_longest = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
@@ -302,8 +303,8 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
     uint2* entries = tmp + L.pair_cap;
     {
         StageTimer t(c, GS4D_T_BINNING);
-        HIPCHK(c, launch_bucket_scan(L.s, L.tl));
-        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, L.host_total_dev, L.pair_cap, tmp, c->tiles_x, c->shard_rank, c->shard_world));
+        HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
+        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, tmp, c->tiles_x, c->shard_rank, c->shard_world));
         HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, L.host_total_dev, tmp, entries, c->list_hint));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event
@@ -397,7 +398,12 @@ int resolve_lane(gs4d_ctx* c, int li) {
         if (L.host_total[4]) return fail(c, GS4D_E_DEVICE, DEVICE_CHECK_MSG);
         const uint64_t total = (uint64_t)L.host_total[2] | ((uint64_t)L.host_total[3] << 32);
         const uint32_t flags = L.host_total[1];
-        if (L.pending_args.v2) c->stat_longest = L.host_total[5];
+        if (L.pending_args.v2) {
+            c->stat_longest = L.host_total[5];
+            // the compositor's occupancy falls with the list capacity it is launched for: give capacity back when the lists stay short
+            const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, L.host_total[5] + L.host_total[5] / 8u));
+            if (!flags && fit < c->list_hint) { if (++c->shrink_votes >= 8) { c->list_hint = fit; c->shrink_votes = 0; } } else c->shrink_votes = 0;
+        }
         if (!flags) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)");
         c->stat_reruns++;
@@ -407,7 +413,7 @@ int resolve_lane(gs4d_ctx* c, int li) {
             // a list longer than the compositor was launched for: grow the LDS list capacity, or leave the unordered path
             const uint32_t longest = L.host_total[5];
             if (longest > V2_MAX_LIST) { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; }
-            else { while (c->list_hint < longest + longest / 4u && c->list_hint < V2_MAX_LIST) c->list_hint *= 2u; if (c->list_hint < longest) c->list_hint = V2_MAX_LIST; }
+            else c->list_hint = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, longest + longest / 8u));
         }
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;

@@ -113,6 +113,12 @@ struct TileCount {                               // hist == nullptr: the ordered
     KeySrc ks;
 };
 constexpr uint32_t V2_MAX_LIST = 2048;           // longest per-tile list the compositor sorts in LDS; beyond it a draw uses the ordered path
+// list capacities the compositor is instantiated for (64 entries per lane-register): the smallest one >= n
+inline uint32_t v2_list_capacity(uint32_t n) {
+    static const uint32_t ladder[] = { 64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048 };
+    for (uint32_t c : ladder) if (n <= c) return c;
+    return V2_MAX_LIST;
+}
 constexpr uint32_t V2_MAX_RECORDS = 1u << 24;    // an entry carries (tile / nb) in the top byte of its record word
 struct TileLists {
     uint32_t* hist = nullptr; size_t hist_cap = 0;            // [nb][rows] counts, turned in place into the slot of every (segment, bucket) run inside its bucket
@@ -125,9 +131,9 @@ bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords);
 hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_t nrecords);
 void tile_lists_free(TileLists& t);
 // total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list,
-// [6] workgroups of k_bucket_tiles that have finished; total_host (pinned, mapped) receives [0..3] and the longest list at [5]
-hipError_t launch_bucket_scan(hipStream_t st, TileLists& t);
-hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, uint32_t* total, uint32_t* total_host, size_t cap, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
+// [6] workgroups of k_bucket_tiles that have finished, [7] of k_bucket_scan (back to 0 when the kernel ends); total_host (pinned, mapped) receives [0..3] and the longest list at [5]
+hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap);
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, const uint2* tmp, uint2* entries, uint32_t hint);
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits);

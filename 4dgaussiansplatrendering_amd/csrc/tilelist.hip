@@ -11,9 +11,9 @@
 //
 //   k_preprocess<.., true>  (preprocess.hip) walks segment w of the records (one workgroup, `seg` records) and leaves
 //                           hist[b][w] = entries its records put into bucket b            (LDS atomics, plain stores)
-//   k_bucket_scan           one wave per bucket: exclusive scan along w -> slot of run (w, b) inside bucket b; bucket totals
-//   k_bucket_scatter        walks the same segments again: entry -> tmp[bucket start + run slot + LDS counter]   (key, tile/nb << 24 | record);
-//                           bucket starts and the capacity check come from the bucket totals (every workgroup scans those 256..1024 numbers)
+//   k_bucket_scan           one wave per bucket: exclusive scan along w -> offs[w][b], the slot of run (w, b) inside bucket b; the workgroup
+//                           that finishes last turns the bucket totals into bucket starts and checks the capacity
+//   k_bucket_scatter        walks the same segments again: entry -> tmp[bucket start + run slot + LDS counter]   (key, tile/nb << 24 | record)
 //   k_bucket_tiles          one workgroup per bucket: counts its entries per tile in LDS, writes the tile table (first entry, count)
 //                           and moves the entries to their tile's list; the longest list is checked against the compositor's capacity
 //   k_composite_v2          (composite2.hip)
@@ -31,31 +31,12 @@ namespace gs4d {
 typedef unsigned long long u64;
 
 
-// hist[b][w] (counts, one row per bucket) -> exclusive scan along w: the slot of run (w, b) inside bucket b; btot[b] = entries of bucket b.
-// One wave per bucket, 64 segments per step: every bucket is scanned in parallel (a single workgroup walking the whole matrix cost 100 us).
-__global__ __launch_bounds__(256) void k_bucket_scan(uint32_t* __restrict__ hist, uint32_t rows, uint32_t nb, uint32_t* __restrict__ btot) {
-    const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (b >= nb) return;
-    uint32_t* __restrict__ h = hist + (size_t)b * rows;
-    uint32_t carry = 0;
-    for (uint32_t w0 = 0; w0 < rows; w0 += 64u) {
-        const uint32_t w = w0 + lane;
-        const uint32_t c = w < rows ? h[w] : 0u;
-        uint32_t inc = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
-        if (w < rows) h[w] = carry + inc - c;
-        carry += __shfl(inc, 63, 64);
-    }
-    if (lane == 0) btot[b] = carry;
-}
-
 // exclusive scan of the bucket totals by a 256-thread workgroup (nb <= 1024): bucket starts into s_base[0..nb], returns the grand total
-__device__ __forceinline__ unsigned long long bucket_bases(const uint32_t* __restrict__ btot, uint32_t nb, uint32_t* s_base /* [1025] */, unsigned long long* s_ws /* [4] */) {
+__device__ __forceinline__ unsigned long long bucket_bases(const uint32_t* btot, uint32_t nb, uint32_t* s_base /* [1025] */, unsigned long long* s_ws /* [4] */) {
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     uint32_t v[4]; unsigned long long sum = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { const uint32_t b = tid * 4u + k; v[k] = b < nb ? btot[b] : 0u; sum += v[k]; }
+    for (int k = 0; k < 4; ++k) { const uint32_t b = tid * 4u + k; v[k] = b < nb ? __hip_atomic_load(btot + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u; sum += v[k]; }
     unsigned long long inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const unsigned long long t = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += t; }
@@ -72,30 +53,62 @@ __device__ __forceinline__ unsigned long long bucket_bases(const uint32_t* __res
     return grand;
 }
 
-// Segment w again: every entry goes to tmp[bucket start + slot of run (w, bucket) + a counter in LDS].  256 threads, one record each per
-// round.  Every workgroup derives the bucket starts from the 256..1024 bucket totals itself; workgroup 0 also leaves them, the entry
-// count and the capacity verdict for the kernels and the host that come after.
-__global__ __launch_bounds__(256) void k_bucket_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t n, uint32_t seg, uint32_t nb, uint32_t rows,
-                                                        const uint32_t* __restrict__ hist, const uint32_t* __restrict__ btot, uint32_t* __restrict__ bbase,
-                                                        uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t cap, uint2* __restrict__ tmp,
-                                                        uint32_t tiles_x, uint32_t shard_rank, uint32_t shard_world) {
-    __shared__ uint32_t cur[1025];
+// hist[b][w] (counts, one row per bucket) -> offs[w][b] = slot of run (w, b) inside bucket b (exclusive scan along w); btot[b] = entries of
+// bucket b.  One wave per bucket; the <= 1024 counts of a bucket are all requested before any is used (a single workgroup walking the
+// whole matrix, load after dependent load, cost 100 us).  The workgroup that finishes last turns the bucket totals into bucket starts and
+// checks the capacity — for the kernels and the host that come after.
+__global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict__ hist, uint32_t rows, uint32_t nb, uint32_t* __restrict__ offs, uint32_t* __restrict__ btot,
+                                                     uint32_t* __restrict__ bbase, uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t cap) {
+    __shared__ uint32_t s_base[1025];
     __shared__ unsigned long long s_ws[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const unsigned long long grand = bucket_bases(btot, nb, cur, s_ws);
-    const bool over = grand > (unsigned long long)cap;
-    if (blockIdx.x == 0) {
-        for (uint32_t b = tid; b <= nb; b += 256u) bbase[b] = cur[b];
-        if (tid == 0) {
-            const uint32_t sat = grand > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)grand;
-            total[0] = sat; total[1] = over ? 1u : 0u; total[2] = (uint32_t)grand; total[3] = (uint32_t)(grand >> 32); total[4] = 0u; total[6] = 0u;
-            // an aborted draw stops here: tell the host now (otherwise k_bucket_tiles reports, once the longest list is known)
-            if (over) { total_host[0] = sat; total_host[1] = 1u; total_host[2] = (uint32_t)grand; total_host[3] = (uint32_t)(grand >> 32); total_host[5] = 0u; }
+    __shared__ uint32_t s_last;
+    const uint32_t lane = threadIdx.x & 63u, b = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (b < nb) {
+        const uint32_t* __restrict__ h = hist + (size_t)b * rows;
+        uint32_t c[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const uint32_t w = (uint32_t)j * 64u + lane; c[j] = w < rows ? h[w] : 0u; }      // rows <= 1024 (tile_lists_plan)
+        uint32_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if ((uint32_t)j * 64u >= rows) break;
+            uint32_t inc = c[j];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
+            const uint32_t w = (uint32_t)j * 64u + lane;
+            if (w < rows) offs[(size_t)w * nb + b] = carry + inc - c[j];
+            carry += __shfl(inc, 63, 64);
         }
+        if (lane == 0) __hip_atomic_store(btot + b, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (over) return;                                      // uniform over the whole grid: slots would lie beyond the capacity
     __syncthreads();
-    for (uint32_t b = tid; b < nb; b += 256u) cur[b] += hist[(size_t)b * rows + blockIdx.x];
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const bool last = atomicAdd(&total[7], 1u) == gridDim.x - 1u;
+        if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); total[7] = 0u; }
+        s_last = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const unsigned long long grand = bucket_bases(btot, nb, s_base, s_ws);
+    for (uint32_t k = threadIdx.x; k <= nb; k += 256u) bbase[k] = s_base[k];
+    if (threadIdx.x == 0) {
+        const bool over = grand > (unsigned long long)cap;
+        const uint32_t sat = grand > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)grand;
+        total[0] = sat; total[1] = over ? 1u : 0u; total[2] = (uint32_t)grand; total[3] = (uint32_t)(grand >> 32); total[4] = 0u; total[6] = 0u;
+        // an aborted draw stops here: tell the host now (otherwise k_bucket_tiles reports, once the longest list is known)
+        if (over) { total_host[0] = sat; total_host[1] = 1u; total_host[2] = (uint32_t)grand; total_host[3] = (uint32_t)(grand >> 32); total_host[5] = 0u; }
+    }
+}
+
+// Segment w again: every entry goes to tmp[bucket start + slot of run (w, bucket) + a counter in LDS].  256 threads, one record each per round.
+__global__ __launch_bounds__(256) void k_bucket_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t n, uint32_t seg, uint32_t nb,
+                                                        const uint32_t* __restrict__ offs, const uint32_t* __restrict__ bbase, const uint32_t* __restrict__ total, uint2* __restrict__ tmp,
+                                                        uint32_t tiles_x, uint32_t shard_rank, uint32_t shard_world) {
+    __shared__ uint32_t cur[1024];
+    if (total[1] & 1u) return;                             // aborted draw: slots would lie beyond the capacity
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t b = tid; b < nb; b += 256u) cur[b] = bbase[b] + offs[(size_t)blockIdx.x * nb + b];
     __syncthreads();
     const uint32_t nbm = nb - 1u, nbs = (uint32_t)__ffs((int)nb) - 1u;
     const uint32_t i0 = blockIdx.x * seg, i1 = min(n, i0 + seg);
@@ -127,19 +140,29 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const uint2* __restrict_
     }
 }
 
-// Bucket b -> the lists of its tiles (tile = h * nb + b, h < 256).  Two sweeps over the bucket's entries: count per tile, then place.
-__global__ __launch_bounds__(1024) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles,
-                                                       uint32_t* __restrict__ tstart, uint32_t* __restrict__ tcnt, uint2* __restrict__ entries,
-                                                       uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t hint) {
+// Bucket b -> the lists of its tiles (tile = h * nb + b, h < 256): count per tile, scan, place.  A thread keeps up to 8 entries in
+// registers (all loads in flight at once); a bucket of up to 8192 entries is read once, a longer one in rounds of 8192, twice.
+constexpr int BT_THREADS = 1024, BT_ITEMS = 8;
+__global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles,
+                                                             uint32_t* __restrict__ tstart, uint32_t* __restrict__ tcnt, uint2* __restrict__ entries,
+                                                             uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t hint) {
     __shared__ uint32_t cnt[256];
     __shared__ uint32_t cur[256];
     __shared__ uint32_t ws[4];
     if (total[1] & 1u) return;                             // capacity overflow (set by k_bucket_scan); bit 1 is raised HERE by other workgroups and must not stop this one
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
     const uint32_t lo = bbase[b], hi = bbase[b + 1];
+    constexpr uint32_t ROUND = BT_THREADS * BT_ITEMS;
+    const bool single = hi - lo <= ROUND;
     if (tid < 256u) cnt[tid] = 0u;
     __syncthreads();
-    for (uint32_t i = lo + tid; i < hi; i += 1024u) atomicAdd(&cnt[tmp[i].y >> 24], 1u);
+    uint2 e[BT_ITEMS];
+    for (uint32_t r0 = lo; r0 < hi; r0 += ROUND) {
+#pragma unroll
+        for (int j = 0; j < BT_ITEMS; ++j) { const uint32_t i = r0 + (uint32_t)j * BT_THREADS + tid; e[j] = i < hi ? tmp[i] : make_uint2(0u, 0xFFFFFFFFu); }
+#pragma unroll
+        for (int j = 0; j < BT_ITEMS; ++j) if (e[j].y != 0xFFFFFFFFu) atomicAdd(&cnt[e[j].y >> 24], 1u);
+    }
     __syncthreads();
     uint32_t c = 0, inc = 0;
     if (tid < 256u) {
@@ -163,10 +186,16 @@ __global__ __launch_bounds__(1024) void k_bucket_tiles(const uint2* __restrict__
         if (lane == 0u && mx) { atomicMax(&total[4], mx); if (mx > hint) atomicOr(&total[1], 2u); }
     }
     __syncthreads();
-    for (uint32_t i = lo + tid; i < hi; i += 1024u) {
-        const uint2 e = tmp[i];
-        const uint32_t pos = atomicAdd(&cur[e.y >> 24], 1u);
-        entries[pos] = make_uint2(e.x, e.y & 0x00FFFFFFu);
+    for (uint32_t r0 = lo; r0 < hi; r0 += ROUND) {
+        if (!single) {
+#pragma unroll
+            for (int j = 0; j < BT_ITEMS; ++j) { const uint32_t i = r0 + (uint32_t)j * BT_THREADS + tid; e[j] = i < hi ? tmp[i] : make_uint2(0u, 0xFFFFFFFFu); }
+        }
+#pragma unroll
+        for (int j = 0; j < BT_ITEMS; ++j) if (e[j].y != 0xFFFFFFFFu) {
+            const uint32_t pos = atomicAdd(&cur[e[j].y >> 24], 1u);
+            entries[pos] = make_uint2(e[j].x, e[j].y & 0x00FFFFFFu);
+        }
     }
     // the last workgroup to finish reports to the host (pinned, mapped memory behind the lane's event)
     __syncthreads();
@@ -199,7 +228,7 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
     if (t.hist_cap < hist_words) {
         if (t.hist) { (void)hipStreamSynchronize(st); (void)hipFree(t.hist); }
         t.hist = nullptr; t.hist_cap = 0;
-        if ((e = hipMalloc(&t.hist, hist_words * 4)) != hipSuccess) return e;
+        if ((e = hipMalloc(&t.hist, hist_words * 8)) != hipSuccess) return e;      // [nb][rows] counts, then [rows][nb] run slots
         t.hist_cap = hist_words;
     }
     if (t.tiles_cap < ntiles || t.nb_cap < t.nb) {
@@ -226,19 +255,18 @@ void tile_lists_free(TileLists& t) {
     t = TileLists();
 }
 
-hipError_t launch_bucket_scan(hipStream_t st, TileLists& t) {
-    k_bucket_scan<<<dim3((t.nb + 3) / 4), dim3(256), 0, st>>>(t.hist, t.rows, t.nb, t.btot);
+hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap) {
+    k_bucket_scan<<<dim3((t.nb + 3) / 4), dim3(256), 0, st>>>(t.hist, t.rows, t.nb, t.hist + t.hist_cap, t.btot, t.bbase, total, total_host, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFull));
     return hipGetLastError();
 }
 
-hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, uint32_t* total, uint32_t* total_host, size_t cap, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
-    k_bucket_scatter<<<dim3(t.rows), dim3(256), 0, st>>>(rects, t.skey, (uint32_t)nrecords, t.seg, t.nb, t.rows, t.hist, t.btot, t.bbase, total, total_host,
-                                                         (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFull), tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
+    k_bucket_scatter<<<dim3(t.rows), dim3(256), 0, st>>>(rects, t.skey, (uint32_t)nrecords, t.seg, t.nb, t.hist + t.hist_cap, t.bbase, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
     return hipGetLastError();
 }
 
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, const uint2* tmp, uint2* entries, uint32_t hint) {
-    k_bucket_tiles<<<dim3(t.nb), dim3(1024), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.tstart, t.tcnt, entries, total, total_host, hint);
+    k_bucket_tiles<<<dim3(t.nb), dim3(BT_THREADS), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.tstart, t.tcnt, entries, total, total_host, hint);
     return hipGetLastError();
 }
 

@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X splat rasteriser (BASELINE.json metric: Gaussians/s + ms/frame @1080p).
 
-A "step" is one frame of the hot path over splat records already resident in HBM:
-    Clear -> key generation -> radix sort -> Draw (preprocess, tile binning, tile sort, composite)
+A "step" is one pass of the hot path over splat records already resident in HBM:
+    Clear -> key generation -> radix sort -> Draw (projection, tile lists, ordered compositing)
 exactly the call sequence of the reference's Scene::Render with sorting on (Scenes.h:312-339), through the C ABI.
 
-  N = 1   workload = BASELINE.json configs[1]: 1,000,000 random 3D splats in a 400^3 cube, one 1080p frame per step.
-  N > 1   independent frames shard over ranks (one process per GPU): every rank renders its own frame
-          of the time sweep per step (4D splats, configs[3] shape) and the finished frames are gathered on rank 0 with
-          one RCCL gather per step in the presentation format (RGBA8).  Weak scaling: per-GPU work is fixed.
+  N = 1   workload = BASELINE.json configs[1]: 1,000,000 random 3D splats in a 400^3 cube, one 1080p frame per step.  The same
+          invocation also times configs[2] (10^7 splats, the HBM-scale config) into the "c3" block of the line, and the frame time
+          with a single frame lane (nothing overlaps: "latency_ms_one_lane").
+  N > 1   workload = BASELINE.json configs[3], exactly: 1,000,000 4D splats, the 256-frame time sweep t_k = 50 k / 255, frame k on rank
+          k mod N (one process per GPU, no data-path collective); the finished frames travel to rank 0 in the presentation format
+          (RGBA8) with one RCCL gather per --gather-every frames of every rank.  A step is one whole sweep (256 frames), so the total
+          work per step is fixed as N grows: "scaling": "strong".
 
-Prints ONE JSON line on rank 0.  `value` = splats processed by all ranks / wall time of the timed region.
+Timing: W untimed warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier + synchronize on both sides, maximum over
+ranks per window; `ms_per_step` / `value` are the MEDIAN window (all windows are listed: a 20-step window lasts 3 ms at N = 1, short
+enough for a clock ramp or a host hiccup to move it by tens of percent; --windows 1 gives the single-window contract reading).
+Prints ONE JSON line on rank 0.  `value` = splats processed by all ranks / wall time.
 """
 import argparse
 import importlib
@@ -27,6 +33,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6.3 TB/s
+SWEEP_FRAMES = 256          # BASELINE.json configs[3]
+PROFILE_TAG = "r02"         # profiles/<tag>_pmc_traffic_c{2,3}.json hold the per-launch HBM traffic of this build's kernels
+
+# stage -> (kernel the stage is made of, launches per frame); "sort" and "pairsort" launch counts come from the library's stats
+KERNELS = {"keygen": "gs4d::k_keygen", "sort": "gs4d::k_os_pass", "preprocess": "gs4d::k_preprocess", "binning": "gs4d::k_bucket_scatter",
+           "pairsort": "gs4d::k_os_pass", "composite": "gs4d::k_composite_v2"}
 
 
 def algorithmic_bytes(n, w, h):
@@ -41,16 +53,145 @@ def algorithmic_bytes(n, w, h):
     }
 
 
+class Scene:
+    """One context with its resident buffers and the per-frame call sequence."""
+
+    def __init__(self, gs4d, records, cam, view, proj, device, keybufs=2, lanes=None):
+        old = os.environ.get("GS4D_LANES")
+        if lanes is not None:
+            os.environ["GS4D_LANES"] = str(lanes)
+        try:
+            self.ctx = gs4d.Context(W, H, device=device)
+        finally:
+            if lanes is not None:
+                if old is None:
+                    os.environ.pop("GS4D_LANES", None)
+                else:
+                    os.environ["GS4D_LANES"] = old
+        self.gs4d, self.n, self.cam = gs4d, records.shape[0], cam
+        ctx = self.ctx
+        self.data = ctx.buffer(records)
+        # per-frame key / sort-index buffers are double-buffered by the application (as any renderer does with per-frame resources):
+        # frame f+1 can generate and sort its keys while frame f is still in flight
+        self.keybufs = [(ctx.buffer(nbytes=4 * self.n), ctx.buffer(nbytes=4 * self.n)) for _ in range(keybufs)]
+        ctx.set_clear_color(gs4d.CLEAR_COLOR)
+        ctx.set_mode(gs4d.MODE_4D_SORTED)
+        ctx.bind(2, self.data)
+        ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+        self.k = 0
+
+    def frame(self, t=0.0):
+        ctx = self.ctx
+        keys, idx = self.keybufs[self.k % len(self.keybufs)]
+        self.k += 1
+        ctx.clear()
+        ctx.set_uniforms(time=t)
+        ctx.keygen(self.data, t, self.cam[0], keys, idx, self.n)
+        ctx.sort_pairs(keys, idx, self.n)
+        ctx.bind(1, idx)
+        ctx.draw_instanced(self.n)
+
+    def close(self):
+        self.ctx.close()
+
+
+def timed_windows(step, fence, steps, warmup, windows, reduce_max=None):
+    """warm-up, then `windows` windows of exactly `steps` steps, each between two fences.  Returns the per-window seconds."""
+    for k in range(warmup):
+        step(k)
+    fence()
+    out = []
+    k = warmup
+    for _ in range(windows):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(k)
+            k += 1
+        fence()
+        el = time.perf_counter() - t0
+        out.append(reduce_max(el) if reduce_max else el)
+    return out
+
+
+def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file):
+    """Dominant credited kernel, priced per launch: achieved = algorithmic bytes per launch / average launch duration from HIP events on the
+    stream the kernel is launched on (gs4d_set_profiling / gs4d_get_timings); traffic = HBM bytes per launch from the rocprofv3 --pmc passes
+    of this command committed under profiles/ (tools/profile_round.sh, tools/pmc_traffic.py)."""
+    alg = algorithmic_bytes(n, W, H)
+    timed = {k: v for k, v in stage_ms.items() if v > 0 and alg[k] > 0}
+    if not timed:
+        return None
+    credited = max(timed, key=timed.get)
+    launches = {"sort": gs4d_stats["depth_sort_passes"], "pairsort": max(1, gs4d_stats["tile_sort_passes"])}.get(credited, 1)
+    kname = KERNELS[credited]
+    ach = alg[credited] / (timed[credited] * 1e-3) / 1e9
+    frame_ach = alg["frame"] / (ms_per_step * 1e-3) / 1e9
+    traffic, tsrc = None, None
+    if os.path.isfile(traffic_file):
+        pm = json.load(open(traffic_file))
+        hit = [v for k, v in pm.items() if k.startswith(kname)]
+        if hit:
+            traffic, tsrc = hit[0]["hbm_bytes_per_launch"], os.path.relpath(traffic_file, ROOT)
+    warm = {k: v for k, v in warm_ms.items() if v > 0}
+    return {"bound": "hbm", "kernel": kname, "stage": credited, "launches_per_frame": launches,
+            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "traffic": traffic, "traffic_source": tsrc,
+            "kernel_ms": round(timed[credited] / launches, 5), "algorithmic_bytes_per_launch": alg[credited] // launches,
+            "note": "consecutive frames overlap on the device (frame lanes, one HIP stream each): a launch timed here runs beside the other lane's kernels and is longer than the same launch alone (profiles/README.md lists both)",
+            "slowest_stage": max(warm, key=warm.get) if warm else None,
+            "frame": {"achieved": round(frame_ach, 2), "frac": round(frame_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": alg["frame"]},
+            "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
+
+
+def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None):
+    """One GPU, static 3D splats in the cube (configs[1] / configs[2]).  Returns (result dict, records)."""
+    cam = scenes.CAM_CUBE
+    view = gs4d.look_at(cam[0], cam[1])
+    proj = gs4d.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
+    pos, q, scale, rgba = scenes.cube_params(n)
+    rec = gs4d.build_records_3d(pos, q, scale, rgba)
+    del pos, q, scale, rgba
+    sc = Scene(gs4d, rec, cam, view, proj, device, lanes=lanes)
+    ctx = sc.ctx
+
+    def fence():
+        ctx.finish()
+
+    # warm-up with every stage timed (HIP events on the launch stream) to find the slowest credited one; in the timed windows only that
+    # stage keeps its events, and only in every 8th frame (an event record costs ~2 us of back-to-back dispatch)
+    ctx.set_profiling(True)
+    for k in range(warmup):
+        sc.frame()
+    fence()
+    warm_ms = ctx.timings()
+    alg = algorithmic_bytes(n, W, H)
+    cred = [k for k, v in warm_ms.items() if v > 0 and alg[k] > 0]
+    dominant = max(cred, key=lambda k: warm_ms[k]) if cred else None
+    ctx.set_profiling([dominant] if (dominant and stage_events) else False, every=8)
+    secs = timed_windows(lambda k: sc.frame(), fence, steps, 0, windows)
+    stage_ms = ctx.timings()
+    ctx.set_profiling(False)
+    stats = ctx.stats()
+    sc.close()
+    ms = sorted(1e3 * s / steps for s in secs)
+    med = ms[len(ms) // 2]
+    res = {"ms_per_step": med, "value": n / (med * 1e-3), "windows_ms_per_step": [round(1e3 * s / steps, 5) for s in secs],
+           "stats": stats, "warm_ms": warm_ms, "stage_ms": stage_ms}
+    return res, rec, (cam, view, proj)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the line reports the median window")
     ap.add_argument("--splats", type=int, default=1_000_000)
-    ap.add_argument("--keybufs", type=int, default=2, help="per-frame key / sort-index buffer pairs the application cycles through")
-    ap.add_argument("--readback", action="store_true", help="N=1 only: also pack every frame to RGBA8 on the device, as the multi-GPU path does before its gather")
+    ap.add_argument("--gather-every", type=int, default=8, help="N>1: frames of every rank per RCCL gather")
+    ap.add_argument("--no-c3", action="store_true", help="N=1: skip the configs[2] block (10^7 splats)")
+    ap.add_argument("--no-latency", action="store_true", help="N=1: skip the one-lane frame time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed region")
+    ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed windows")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,173 +207,133 @@ def main():
     if backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    dist = None
-    if multi:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
 
+    if not multi:
+        out = single_gpu(args, gs4d, scenes, local_rank)
+    else:
+        out = multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def single_gpu(args, gs4d, scenes, device):
+    n = args.splats
+    res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events)
+    tfile = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{'c2' if n == 1_000_000 else 'c3' if n == 10_000_000 else 'x'}.json")
+    roofline = roofline_block(res["stats"], res["stage_ms"], res["warm_ms"], n, res["ms_per_step"], tfile)
+    latency = None
+    if not args.no_latency:
+        one, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=1)
+        latency = round(one["ms_per_step"], 5)
+    c3 = None
+    if not args.no_c3 and n == 1_000_000:
+        n3 = 10_000_000
+        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 5, 3, device, stage_events=not args.no_stage_events)
+        c3 = {"workload": "10,000,000 random 3D splats in a 400^3 cube, single 1080p frame (BASELINE.json configs[2])", "splats": n3,
+              "ms_per_step": r3["ms_per_step"], "value": r3["value"], "unit": "splats/s", "windows_ms_per_step": r3["windows_ms_per_step"],
+              "tile_list_entries": r3["stats"]["entries"], "longest_tile_list": r3["stats"]["longest_list"], "unordered_draws": r3["stats"]["unordered_draws"],
+              "roofline": roofline_block(r3["stats"], r3["stage_ms"], r3["warm_ms"], n3, r3["ms_per_step"], os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_c3.json"))}
+    cpu = None if args.no_cpu_baseline else cpu_baseline(rec, cam, view, proj)
+    st = res["stats"]
+    return {
+        "metric": "Gaussians/sec + ms/frame @1080p; sort permutation bit-exact",
+        "value": res["value"], "unit": "splats/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "timing": f"median of {args.windows} windows of {args.steps} steps, each window between two synchronisations; a step is pipelined throughput (two frame lanes in flight)",
+        "windows_ms_per_step": res["windows_ms_per_step"],
+        "latency_ms_one_lane": latency,
+        "config": {"workload": f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else ""),
+                   "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": 1, "frame_lanes": st["lanes"],
+                   "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "overflow_reruns": st["reruns"]},
+        "roofline": roofline,
+        "c3": c3,
+        "cpu_baseline": cpu,
+    }
+
+
+def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
+    import torch.distributed as dist
+    sharding = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
     n = args.splats
     cam = scenes.CAM_CUBE
     view = gs4d.look_at(cam[0], cam[1])
     proj = gs4d.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
-    if multi:
-        pos4, q, scale, life, fade, vel, rgba = scenes.cube_params_4d(n)
-        rec = gs4d.build_records_4d(pos4, q, scale, life, fade, vel, rgba)
-    else:
-        pos, q, scale, rgba = scenes.cube_params(n)
-        rec = gs4d.build_records_3d(pos, q, scale, rgba)
-
-    ctx = gs4d.Context(W, H, device=local_rank)
-    if multi:
-        # torch's stream becomes the caller's stream: the packed frame is ordered before the gather that sends it, and the next
-        # frame's pack after the gather that still reads the buffer
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    data = ctx.buffer(rec)
-    # per-frame key / sort-index buffers are double-buffered by the application (as any renderer does with per-frame resources):
-    # frame f+1 can generate and sort its keys while frame f's binning still reads frame f's sort index
-    keybufs = [(ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)) for _ in range(args.keybufs)]
-    ctx.set_clear_color(gs4d.CLEAR_COLOR)
-    ctx.set_mode(gs4d.MODE_4D_SORTED)
-    ctx.bind(2, data)
-    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
-
-    frame8 = gathered = None
+    pos4, q, scale, life, fade, vel, rgba = scenes.cube_params_4d(n)
+    rec = gs4d.build_records_4d(pos4, q, scale, life, fade, vel, rgba)
+    sc = Scene(gs4d, rec, cam, view, proj, local_rank)
+    ctx = sc.ctx
+    # torch's stream becomes the caller's stream: a packed frame is ordered before the gather that sends it, and the next pack into
+    # the same slot after the gather that still reads it
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     gdev = "cuda" if backend == "nccl" else "cpu"
-    if multi or args.readback:
-        frame8 = torch.empty(H * W, dtype=torch.int32, device="cuda")
-    if multi:
-        gathered = [torch.empty(H * W, dtype=torch.int32, device=gdev) for _ in range(world)] if rank == 0 else None
+    G = max(1, args.gather_every)
+    mine = sharding.frames_for_rank(SWEEP_FRAMES, rank, world)            # frame k -> rank k mod world
+    most = len(sharding.frames_for_rank(SWEEP_FRAMES, 0, world))          # ranks with fewer frames pad their last batch
+    batch = torch.zeros((G, H * W), dtype=torch.int32, device="cuda")
+    gathered = [torch.empty((G, H * W), dtype=torch.int32, device=gdev) for _ in range(world)] if rank == 0 else None
+    pipelined = ctx.stats()["lanes"] >= 2                                 # with one frame lane there is no previous image to read
 
-    sharding = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
-    total_frames = (args.warmup + args.steps) * world
-
-    def step(k):
-        # frame of this rank in the time sweep (frame f -> rank f mod world); static 3D records ignore t
-        t = sharding.sweep_time(sharding.frame_of(k, rank, world), total_frames) if multi else 0.0
-        keys, idx = keybufs[k % args.keybufs]
-        ctx.clear()
-        ctx.set_uniforms(time=t)
-        ctx.keygen(data, t, cam[0], keys, idx, n)
-        ctx.sort_pairs(keys, idx, n)
-        ctx.bind(1, idx)
-        ctx.draw_instanced(n)
-        # Presentation is software-pipelined, as a swap chain is: frame k is queued first, then frame k-1 (the previous image) is
-        # packed to RGBA8 and gathered — its lane finished long ago, so the host never waits for the frame it has just queued.
-        if multi or args.readback:
-            if not pipelined:
-                present(0)
-                return
-            if state["unsent"]:
-                present(1)
-        state["unsent"] = True
-
-    state = {"unsent": False}
-    pipelined = ctx.stats()["lanes"] >= 2          # with one frame lane there is no previous image to read
-
-    def present(frames_back):
-        ctx.read_frame_rgba8_device(frames_back, frame8.data_ptr(), frame8.numel() * 4)
-        if multi:
-            sharding.gather_frames(dist, frame8 if backend == "nccl" else frame8.cpu(), gathered, dst=0)
-        state["unsent"] = False
-
-    def flush():
-        # the last frame of a region is presented inside that region: K steps render K frames and gather K frames
-        if (multi or args.readback) and state["unsent"]:
-            present(0)
-        state["unsent"] = False
+    def sweep(_k):
+        """One step: this rank's frames of the 256-frame sweep; presentation is software-pipelined as a swap chain is — frame j is queued
+        first, then frame j-1 (the previous image) is packed to RGBA8 into the batch; every G frames the batch is gathered on rank 0."""
+        slot, pending = 0, False
+        for j in range(most):
+            if j < len(mine):
+                sc.frame(sharding.sweep_time(mine[j], SWEEP_FRAMES))
+                if pipelined and pending:
+                    ctx.read_frame_rgba8_device(1, batch[slot].data_ptr(), H * W * 4)
+                    slot += 1
+                elif not pipelined:
+                    ctx.read_frame_rgba8_device(0, batch[slot].data_ptr(), H * W * 4)
+                    slot += 1
+                pending = pipelined
+            last = j == most - 1
+            if last and pending:                                          # the last frame of the sweep is presented inside the sweep
+                ctx.read_frame_rgba8_device(0, batch[slot].data_ptr(), H * W * 4)
+                slot += 1
+                pending = False
+            if slot == G or (last and slot > 0) or (last and world > 1 and (most % G) and slot == 0 and j >= len(mine)):
+                sharding.gather_frames(dist, batch if backend == "nccl" else batch.cpu(), gathered, dst=0)
+                slot = 0
 
     def fence():
-        flush()
         ctx.finish()
         torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-            torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
 
-    # Warm-up: time every stage (HIP events on the launch stream) to find the slowest one.  In the timed region only that stage
-    # keeps its pair of events: every timed stage costs two event records per frame, and six of them cost ~7 % of a 0.3 ms frame.
-    ctx.set_profiling(True)
-    for k in range(args.warmup):
-        step(k)
-    fence()
-    warm_ms = ctx.timings()
-    alg0 = algorithmic_bytes(n, W, H)
-    credited = [k for k, v in warm_ms.items() if v > 0 and alg0[k] > 0]
-    dominant = max(credited, key=lambda k: warm_ms[k]) if credited else None
-    # timed region: only the slowest credited stage keeps its events, and only in every 8th frame (an event record is a marker packet
-    # between two kernels of the lane: it costs ~2 us of back-to-back dispatch; sampled, the bench runs at the un-instrumented rate)
-    ctx.set_profiling([dominant] if (dominant and not args.no_stage_events) else False, every=8)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    fence()
-    elapsed = time.perf_counter() - t0
-    stage_ms = ctx.timings()
-    ctx.set_profiling(False)
-    stats = ctx.stats()
-
-    if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
+    def reduce_max(el):
+        tt = torch.tensor([el], dtype=torch.float64, device=gdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = n * args.steps * world / elapsed
-
-    if rank == 0:
-        alg = algorithmic_bytes(n, W, H)
-        timed = {k: v for k, v in stage_ms.items() if v > 0}
-        warm = {k: v for k, v in warm_ms.items() if v > 0}
-        dom = max(warm, key=warm.get) if warm else None
-        # The dominant credited stage keeps its HIP events in the timed region.  A stage is `launches` launches of one kernel; achieved =
-        # algorithmic bytes per launch / average launch duration (same ratio as stage bytes / stage time).  HBM traffic per launch comes
-        # from the rocprofv3 --pmc passes of this very command committed under profiles/ (FETCH_SIZE doubled, KiB units; tools/pmc_traffic.py).
-        KERNEL = {"keygen": ("gs4d::k_keygen", 1), "sort": ("gs4d::k_os_pass", stats["depth_sort_passes"]), "preprocess": ("gs4d::k_preprocess_4d", 1),
-                  "binning": ("gs4d::k_bin_emit", 1), "pairsort": ("gs4d::k_os_pass", stats["tile_sort_passes"]), "composite": ("gs4d::k_composite<false>", 1)}
-        roofline = None
-        if timed:
-            credited = max(timed, key=timed.get)
-            kname, launches = KERNEL[credited]
-            ach = alg[credited] / (timed[credited] * 1e-3) / 1e9
-            frame_ach = alg["frame"] / (ms_per_step * 1e-3) / 1e9
-            traffic, tsrc = None, None
-            tfile = os.path.join(ROOT, "profiles", {1_000_000: "r01_c_pmc_traffic_c2.json", 10_000_000: "r01_c_pmc_traffic_c3.json"}.get(n, ""))
-            if os.path.isfile(tfile):
-                pm = json.load(open(tfile))
-                hit = [v for k, v in pm.items() if k.startswith(kname)]
-                if hit:
-                    traffic, tsrc = hit[0]["hbm_bytes_per_launch"], os.path.relpath(tfile, ROOT)
-            roofline = {"bound": "hbm", "kernel": kname, "stage": credited, "launches_per_frame": launches,
-                        "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                        "traffic": traffic, "traffic_source": tsrc,
-                        "kernel_ms": round(timed[credited] / launches, 5), "algorithmic_bytes_per_launch": alg[credited] // launches,
-                        "note": "consecutive frames overlap on the device (frame lanes, one HIP stream each): a launch timed here runs beside the other lane's kernels and is longer than the same launch alone (profiles/README.md lists both)",
-                        "slowest_stage": dom,
-                        "frame": {"achieved": round(frame_ach, 2), "frac": round(frame_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": alg["frame"]},
-                        "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
-        cpu = None
-        if not args.no_cpu_baseline and not multi:
-            cpu = cpu_baseline(rec, cam, view, proj)
-        out = {
-            "metric": "Gaussians/sec + ms/frame @1080p; sort permutation bit-exact",
-            "value": value, "unit": "splats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else "") if not multi else
-                                    "1,000,000 4D splats, time sweep, one 1080p frame per rank per step, RGBA8 frames gathered on rank 0 (BASELINE.json configs[3] shape)"),
-                       "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": world, "frame_lanes": stats["lanes"],
-                       "tile_list_entries": stats["entries"], "overflow_reruns": stats["reruns"]},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-        }
-        print(json.dumps(out), flush=True)
-
-    ctx.close()
-    if multi:
-        dist.destroy_process_group()
+    secs = timed_windows(sweep, fence, args.steps, args.warmup, args.windows, reduce_max)
+    stats = ctx.stats()
+    sc.close()
+    dist.destroy_process_group()
+    ms = sorted(1e3 * s / args.steps for s in secs)
+    med = ms[len(ms) // 2]
+    alg = algorithmic_bytes(n, W, H)
+    frame_ach = alg["frame"] * SWEEP_FRAMES / (med * 1e-3) / 1e9
+    return {
+        "metric": "Gaussians/sec + ms/frame @1080p; sort permutation bit-exact",
+        "value": n * SWEEP_FRAMES / (med * 1e-3), "unit": "splats/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": med, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "timing": f"median of {args.windows} windows of {args.steps} steps (a step = the whole {SWEEP_FRAMES}-frame sweep), barrier + synchronize around every window, maximum over ranks",
+        "windows_ms_per_step": [round(1e3 * s / args.steps, 4) for s in secs],
+        "config": {"workload": "1,000,000 4D splats, 256-frame time sweep t_k = 50 k / 255, frame k on rank k mod N, RGBA8 frames gathered on rank 0 (BASELINE.json configs[3])",
+                   "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": SWEEP_FRAMES, "ms_per_frame": med / SWEEP_FRAMES,
+                   "frames_per_gather_per_rank": G, "frame_lanes": stats["lanes"], "tile_list_entries": stats["entries"], "overflow_reruns": stats["reruns"]},
+        "roofline": {"bound": "hbm", "kernel": None, "achieved": round(frame_ach, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(frame_ach / (HBM_PEAK_GBS * world), 5),
+                     "traffic": None, "note": "whole-job algorithmic bytes over all ranks against N x 8 TB/s; the per-kernel figure is in the N = 1 line"},
+        "cpu_baseline": None,
+    }
 
 
 def cpu_baseline(rec, cam, view, proj, budget_s=(12.0, 6.0)):

@@ -9,7 +9,6 @@
   live digit (sort contract: radix_sort.hpp:258-392).
 Bars: bit-exact for keys and permutations; per-pixel L-infinity <= 1e-4 for float images; <= 1 count for RGBA8.
 """
-import ctypes as C
 import os
 
 import numpy as np
@@ -208,70 +207,14 @@ def test_sort_with_one_live_digit(gs4d, oracle, monkeypatch, n, pattern):
     ctx.close()
 
 
-def _rgba8(img):
-    q = np.rint(np.clip(img.astype(np.float64), 0.0, 1.0) * 255.0).astype(np.uint32)
-    return q[..., 0] | (q[..., 1] << 8) | (q[..., 2] << 16) | (q[..., 3] << 24)
-
-
-def _max_count_diff(a, b):
-    d = 0
-    for s in (0, 8, 16, 24):
-        d = max(d, int(np.abs(((a >> s) & 255).astype(np.int64) - ((b >> s) & 255).astype(np.int64)).max()))
-    return d
-
-
-def test_caller_stream_handoff_with_refilled_device_buffer(gs4d, oracle, monkeypatch):
-    """The multi-GPU hand-off without the collective: the caller refills the record buffer through its device pointer on ITS stream,
-    renders, reads the frame back on the device and consumes it on its stream — frame after frame, two frame lanes in flight."""
-    torch = pytest.importorskip("torch")
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    hip.hipMemcpyAsync.restype = C.c_int
-    n, W, H = 50000, 640, 360
-    cam = scenes.CAM_CUBE
-    ctx = _ctx(gs4d, W, H, monkeypatch)
-    view, proj = cam_mats(gs4d, cam, W, H)
-    recs = []
-    for seed in (71, 72, 73):
-        pos, q, sc, rgba = scenes.cube_params(n, seed=seed)
-        recs.append(gs4d.build_records_3d(pos, q, sc * 4.0, rgba))
-    side = torch.cuda.Stream()
-    ctx.set_stream(side.cuda_stream)
-    data = ctx.buffer(nbytes=96 * n)
-    dptr, nbytes = ctx.device_ptr(data)
-    assert nbytes == 96 * n
-    kb, ib = ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
-    ctx.set_clear_color(gs4d.CLEAR_COLOR)
-    ctx.set_mode(gs4d.MODE_4D_SORTED)
-    ctx.bind(2, data)
-    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
-    outs8, outsf = [], []
-    with torch.cuda.stream(side):
-        for rec in recs:
-            src = torch.from_numpy(rec).to("cuda", non_blocking=False)
-            ctx.invalidate(data)                                   # the side stream now waits for the frames that still read `data`
-            assert hip.hipMemcpyAsync(dptr, src.data_ptr(), 96 * n, 3, C.c_void_p(side.cuda_stream)) == 0
-            ctx.clear()
-            ctx.keygen(data, 0.0, cam[0], kb, ib, n)
-            ctx.sort_pairs(kb, ib, n)
-            ctx.bind(1, ib)
-            ctx.draw_instanced(n)
-            f8 = torch.empty(H * W, dtype=torch.int32, device="cuda")
-            ff = torch.empty(H * W * 4, dtype=torch.float32, device="cuda")
-            ctx.read_pixels_rgba8_device(f8.data_ptr(), f8.numel() * 4)
-            ctx.read_pixels_device(ff.data_ptr(), ff.numel() * 4)
-            outs8.append(f8.to("cpu", non_blocking=True))          # consumed on the caller's stream, no host synchronisation in between
-            outsf.append(ff.to("cpu", non_blocking=True))
-            del src
-    side.synchronize()
-    ctx.finish()
-    for rec, f8, ff in zip(recs, outs8, outsf):
-        eimg, _, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
-        assert linf(ff.numpy().reshape(H, W, 4), eimg) <= TOL
-        assert _max_count_diff(f8.numpy().view(np.uint32).reshape(H, W), _rgba8(eimg)) <= 1
-    assert linf(outsf[0].numpy(), outsf[1].numpy()) > 0.05           # the three frames do differ: stale records would be noticed
-    ctx.set_stream(None)
-    ctx.close()
+def test_caller_stream_handoff_with_refilled_device_buffer():
+    """gs4d_set_stream + gs4d_buffer_device_ptr / gs4d_buffer_invalidate + device read-backs, consumed on a torch side stream: run as a
+    program of its own (tests/gpu_stream_handoff.py) because torch has to initialise its HIP runtime before libgs4d.so is loaded."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_stream_handoff.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "stream hand-off ok" in r.stdout
 
 
 def _grid_vertices(width, height, dx, dy):

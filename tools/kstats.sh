@@ -21,4 +21,4 @@ for r in rows:
         tot += avg * calls / frames
 print(f"  sum per frame {tot:9.1f} us")
 PY
-tail -c 400 gpurun_out/${tag}_trace.log | grep -o '"ms_per_step": [0-9.]*'
+grep -o "\"ms_per_step\": [0-9.]*" gpurun_out/${tag}_trace.log | head -1 || true
