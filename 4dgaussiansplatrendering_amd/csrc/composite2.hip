@@ -61,7 +61,7 @@ struct WaveSort {
 template <bool PREMULT_C, int PER>
 __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
                                                      const uint32_t* __restrict__ total, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
-                                                     float4* __restrict__ fb, int key_passes, int rec_passes) {
+                                                     float4* __restrict__ fb, int key_passes, int rec_passes, uint32_t slabs) {
     // the sort's key plane and the blend's record staging never live at the same time: one piece of LDS serves both
     constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
     __shared__ __attribute__((aligned(16))) uint32_t sh_a[SHARED_WORDS];
@@ -76,44 +76,47 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE;
     const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    const uint32_t start = tstart[tile];
-    const uint32_t E = min(tcnt[tile], (uint32_t)(64 * PER));                    // k_bucket_tiles guarantees the bound; min() keeps a broken promise inside LDS
-
-    if (E > 1u) {
-        WaveSort<PER> ws;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) {
-            ws.k[j] = 0u; ws.r[j] = 0u;
-            if ((uint32_t)j * 64u + lane < E) { const uint2 e = entries[start + j * 64 + lane]; ws.k[j] = e.x; ws.r[j] = e.y; }
-        }
-        for (int p = 0; p < key_passes; ++p) ws.pass(false, 6 * p, E, ek, er, cnt, lane);
-        // the sorted keys go to LDS for the neighbour test (the last pass may have been an identity that wrote nothing)
-#pragma unroll
-        for (int j = 0; j < PER; ++j) { if ((uint32_t)j * 64u + lane < E) { ek[j * 64 + lane] = ws.k[j]; er[j * 64 + lane] = ws.r[j]; } }
-        __syncthreads();
-        bool tie = false;
-#pragma unroll
-        for (int j = 0; j < PER; ++j) { const uint32_t i = (uint32_t)j * 64u + lane; if (i + 1u < E) tie |= ek[i] == ek[i + 1u]; }
-        if (__ballot(tie) != 0ull) {                        // equal keys: instance order among them is ascending record index
-            __syncthreads();
-            for (int p = 0; p < rec_passes; ++p) ws.pass(true, 6 * p, E, ek, er, cnt, lane);
-            for (int p = 0; p < key_passes; ++p) ws.pass(false, 6 * p, E, ek, er, cnt, lane);
-#pragma unroll
-            for (int j = 0; j < PER; ++j) { if ((uint32_t)j * 64u + lane < E) er[j * 64 + lane] = ws.r[j]; }
-        }
-        __syncthreads();
-    } else if (E == 1u) {
-        if (lane == 0) er[0] = entries[start].y;
-        __syncthreads();
-    }
-
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
-    for (uint32_t hi = E; hi > 0u;) {
-        const uint32_t c = min(64u, hi);
-        const uint32_t rec = lane < c ? er[hi - 1u - lane] : 0u;       // lane s holds list entry hi-1-s : s = 0 is the front-most of the chunk
-        composite_chunk<PREMULT_C>(proj, rec, c, lane, tx0, ty0, fx, fy, stage, pmask, 0, T, Cr, Cg, Cb, A);
-        hi -= c;
-        if (__ballot(T > 0.0f) == 0ull) break;              // exact: every remaining contribution is multiplied by T == 0
+    // the tile's list is `slabs` sub-lists by the top bits of the key; larger key = nearer: the last slab is blended first
+    for (int sb = (int)slabs - 1; sb >= 0; --sb) {
+        const uint32_t start = tstart[(size_t)tile * slabs + sb];
+        const uint32_t E = min(tcnt[(size_t)tile * slabs + sb], (uint32_t)(64 * PER));       // k_bucket_tiles guarantees the bound; min() keeps a broken promise inside LDS
+        if (E == 0u) continue;
+        if (E > 1u) {
+            WaveSort<PER> ws;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                ws.k[j] = 0u; ws.r[j] = 0u;
+                if ((uint32_t)j * 64u + lane < E) { const uint2 e = entries[start + j * 64 + lane]; ws.k[j] = e.x; ws.r[j] = e.y; }
+            }
+            for (int p = 0; p < key_passes; ++p) ws.pass(false, 6 * p, E, ek, er, cnt, lane);
+            // the sorted keys go to LDS for the neighbour test (the last pass may have been an identity that wrote nothing)
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { if ((uint32_t)j * 64u + lane < E) { ek[j * 64 + lane] = ws.k[j]; er[j * 64 + lane] = ws.r[j]; } }
+            __syncthreads();
+            bool tie = false;
+#pragma unroll
+            for (int j = 0; j < PER; ++j) { const uint32_t i = (uint32_t)j * 64u + lane; if (i + 1u < E) tie |= ek[i] == ek[i + 1u]; }
+            if (__ballot(tie) != 0ull) {                    // equal keys: instance order among them is ascending record index
+                __syncthreads();
+                for (int p = 0; p < rec_passes; ++p) ws.pass(true, 6 * p, E, ek, er, cnt, lane);
+                for (int p = 0; p < key_passes; ++p) ws.pass(false, 6 * p, E, ek, er, cnt, lane);
+#pragma unroll
+                for (int j = 0; j < PER; ++j) { if ((uint32_t)j * 64u + lane < E) er[j * 64 + lane] = ws.r[j]; }
+            }
+            __syncthreads();
+        } else {
+            if (lane == 0) er[0] = entries[start].y;
+            __syncthreads();
+        }
+        for (uint32_t hi = E; hi > 0u;) {
+            const uint32_t c = min(64u, hi);
+            const uint32_t rec = lane < c ? er[hi - 1u - lane] : 0u;       // lane s holds list entry hi-1-s : s = 0 is the front-most of the chunk
+            composite_chunk<PREMULT_C>(proj, rec, c, lane, tx0, ty0, fx, fy, stage, pmask, 0, T, Cr, Cg, Cb, A);
+            hi -= c;
+            if (__ballot(T > 0.0f) == 0ull) break;          // exact: every remaining contribution is multiplied by T == 0
+        }
+        if (__ballot(T > 0.0f) == 0ull) break;
     }
     if (px < W && py < H) {
         const size_t o = (size_t)py * W + px;
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
 
 template <bool PREMULT_C>
 static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int W, int H,
-                            int fb_is_clear, float4 c, float4* fb, int kp, int rp) {
-#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp)
+                            int fb_is_clear, float4 c, float4* fb, int kp, int rp, uint32_t slabs) {
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
@@ -143,14 +146,14 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
 }
 
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
-                               int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits) {
+                               int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs) {
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid((unsigned)(tiles_x * tiles_y));
     const int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
-    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp)
-                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp);
+    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
+                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs);
 }
 
 } // namespace gs4d

@@ -120,7 +120,8 @@ struct gs4d_ctx {
     int path_pref = 0;                 // GS4D_DRAW_PATH: 0 auto, 1 ordered path only, 2 = auto (kept for symmetry)
     bool long_lists = false;           // the last unordered draw met a list longer than V2_MAX_LIST: draws use the ordered path ...
     uint64_t ordered_draws = 0;        // ... and probe the unordered one again every so often when the lists look short on average
-    int shrink_votes = 0;
+    int shrink_votes = 0, unslab_votes = 0;
+    uint32_t slabs = 1;                // depth slabs per tile list (tilelist.hip): doubled when a list outgrows V2_MAX_LIST, given back when the lists stay short
     uint32_t list_hint = 256;          // LDS list capacity the compositor is launched with (64 << k); grows on demand, validated per draw on the device
     uint64_t stat_v2_draws = 0, stat_longest = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
@@ -313,7 +314,7 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
         StageTimer t(c, GS4D_T_COMPOSITE);
         int recbits = 1; while (recbits < 32 && ((size_t)1 << recbits) < nrecords) ++recbits;
         HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, c->clear, F.mem,
-                                      c->list_hint, a.keybits, recbits));
+                                      c->list_hint, a.keybits, recbits, L.tl.slabs));
     }
     return GS4D_OK;
 }
@@ -342,7 +343,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
-    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre);
+    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, c->slabs, a.keybits);
     if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
     uint32_t* order_copy = nullptr;
     if (order) {
@@ -403,6 +404,7 @@ int resolve_lane(gs4d_ctx* c, int li) {
             // the compositor's occupancy falls with the list capacity it is launched for: give capacity back when the lists stay short
             const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, L.host_total[5] + L.host_total[5] / 8u));
             if (!flags && fit < c->list_hint) { if (++c->shrink_votes >= 8) { c->list_hint = fit; c->shrink_votes = 0; } } else c->shrink_votes = 0;
+            if (!flags && c->slabs > 1u && L.host_total[5] * 3u < V2_MAX_LIST) { if (++c->unslab_votes >= 8) { c->slabs /= 2u; c->list_hint = V2_MAX_LIST; c->unslab_votes = 0; } } else c->unslab_votes = 0;
         }
         if (!flags) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)");
@@ -412,7 +414,13 @@ int resolve_lane(gs4d_ctx* c, int li) {
         if (L.pending_args.v2 && (flags & 2u)) {
             // a list longer than the compositor was launched for: grow the LDS list capacity, or leave the unordered path
             const uint32_t longest = L.host_total[5];
-            if (longest > V2_MAX_LIST) { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; }
+            if (longest > V2_MAX_LIST) {
+                // cut the lists into more depth slabs (each sub-list is ordered by itself); past the last doubling: the ordered path
+                uint32_t want = c->slabs;
+                while (want < V2_MAX_SLABS && (uint64_t)longest * c->slabs > (uint64_t)want * (V2_MAX_LIST - V2_MAX_LIST / 4u)) want *= 2u;
+                if (want > c->slabs && (1u << std::min(31, L.pending_args.keybits)) >= want) { c->slabs = want; c->list_hint = V2_MAX_LIST; }
+                else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; }
+            }
             else c->list_hint = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, longest + longest / 8u));
         }
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));

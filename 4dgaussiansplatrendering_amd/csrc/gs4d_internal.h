@@ -108,11 +108,13 @@ struct TileCount {                               // hist == nullptr: the ordered
     uint32_t* hist = nullptr;                    // [nb][rows]: entries that the records of segment `row` put into bucket b = tile % nb
     uint32_t rows = 0;
     uint32_t* skey = nullptr;                    // [records] blend-order key of every record
-    uint32_t nb = 0, seg = 0;                    // buckets (a power of two), records per segment (a multiple of 256; one workgroup walks one segment)
+    uint32_t nb = 0, seg = 0;                    // buckets (a power of two), records per segment (a multiple of SEG_THREADS; one workgroup walks one segment)
     int tiles_x = 0, shard_rank = 0, shard_world = 1;
     KeySrc ks;
 };
-constexpr uint32_t V2_MAX_LIST = 2048;           // longest per-tile list the compositor sorts in LDS; beyond it a draw uses the ordered path
+constexpr uint32_t V2_MAX_LIST = 2048;           // longest list the compositor sorts in LDS.  Longer per-tile lists are cut into depth slabs (below); beyond V2_MAX_SLABS a draw uses the ordered path
+constexpr uint32_t V2_MAX_SLABS = 16;            // a tile's list is kept as `slabs` sub-lists by the top bits of the blend key: far slab first, each ordered by itself in the compositor
+constexpr int SEG_THREADS = 512;                 // workgroup size of the kernels that walk a segment of records (k_preprocess<.., true>, k_bucket_scatter)
 // list capacities the compositor is instantiated for (64 entries per lane-register): the smallest one >= n
 inline uint32_t v2_list_capacity(uint32_t n) {
     static const uint32_t ladder[] = { 64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048 };
@@ -124,10 +126,10 @@ struct TileLists {
     uint32_t* hist = nullptr; size_t hist_cap = 0;            // [nb][rows] counts, turned in place into the slot of every (segment, bucket) run inside its bucket
     uint32_t* bbase = nullptr; uint32_t* btot = nullptr; uint32_t* tstart = nullptr; uint32_t* tcnt = nullptr; size_t tiles_cap = 0, nb_cap = 0;   // [nb + 1] bucket starts, [nb] bucket totals; per tile: first entry, entries
     uint32_t* skey = nullptr; size_t skey_cap = 0;
-    uint32_t nb = 0, rows = 0, seg = 0;                       // geometry of the current draw (tile_lists_plan)
+    uint32_t nb = 0, rows = 0, seg = 0, slabs = 1, slab_shift = 0;   // geometry of the current draw (tile_lists_plan): slab of an entry = min(slabs - 1, key >> slab_shift)
 };
 // false: this frame / record count cannot use the unordered path (more than 256 * 1024 tiles, or 2^24 records)
-bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords);
+bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits);
 hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_t nrecords);
 void tile_lists_free(TileLists& t);
 // total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list,
@@ -136,7 +138,7 @@ hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uin
 hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, const uint2* tmp, uint2* entries, uint32_t hint);
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
-                               int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits);
+                               int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs);
 
 #ifdef __HIPCC__
 // tiles touched by a pixel rectangle (x0|y0<<16, x1|y1<<16; x0 > x1: none), restricted to the tile rows ty % world == rank
@@ -157,6 +159,11 @@ __device__ __forceinline__ TRect tile_rect(uint32_t rect0, uint32_t rect1, uint3
     return r;
 }
 __device__ __forceinline__ uint32_t tile_of(const TRect& r, uint32_t j, uint32_t tiles_x) { return (r.ty0 + (j / r.wx) * r.tstep) * tiles_x + r.tx0 + j % r.wx; }
+// every tile of a small footprint, row by row (no division: this runs once per record in two kernels)
+template <class F> __device__ __forceinline__ void for_each_tile(const TRect& r, uint32_t tiles_x, F f) {
+    uint32_t rowbase = r.ty0 * tiles_x + r.tx0;
+    for (uint32_t y = 0; y < r.rows; ++y) { for (uint32_t x = 0; x < r.wx; ++x) f(rowbase + x); rowbase += r.tstep * tiles_x; }
+}
 #endif
 
 // ---- preprocess.hip ----

@@ -153,7 +153,7 @@ __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid,
 // whole wave.
 __device__ __forceinline__ void count_buckets(uint32_t* h, uint32_t nbm, uint32_t tiles_x, const TRect& r) {
     const bool big = r.count > 16u;
-    if (!big) for (uint32_t j = 0; j < r.count; ++j) atomicAdd(&h[tile_of(r, j, tiles_x) & nbm], 1u);
+    if (!big) for_each_tile(r, tiles_x, [&](uint32_t t) { atomicAdd(&h[t & nbm], 1u); });
     uint64_t m = __ballot(big);
     const uint32_t lane = threadIdx.x & 63u;
     while (m) {
@@ -300,22 +300,23 @@ __device__ __forceinline__ uint2 project_record(const Src2D& src, uint32_t, uint
     return emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
 }
 
-// COUNT == false: one thread per record (the ordered path).  COUNT == true: workgroup w walks records [w * seg, (w + 1) * seg), 256 per
-// round, and leaves row w of the bucket histogram.
-template <class SRC, bool COUNT>
+// One thread per record (the ordered path).
+template <class SRC>
 __global__ __launch_bounds__(256) void k_preprocess(SRC src, uint32_t n, PU u, PreOut out, TileCount tc) {
-    if (!COUNT) {
-        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-        if (i >= n) return;
-        uint32_t key;
-        (void)project_record(src, n, i, u, out, tc.ks, key);
-        return;
-    }
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t key;
+    (void)project_record(src, n, i, u, out, tc.ks, key);
+}
+
+// Unordered path: workgroup w walks records [w * seg, (w + 1) * seg), SEG_THREADS per round, and leaves the counts of its segment per bucket.
+template <class SRC>
+__global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t n, PU u, PreOut out, TileCount tc) {
     __shared__ uint32_t h[1024];
-    for (uint32_t b = threadIdx.x; b < tc.nb; b += 256u) h[b] = 0u;
+    for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) h[b] = 0u;
     __syncthreads();
     const uint32_t i0 = blockIdx.x * tc.seg, i1 = min(n, i0 + tc.seg);
-    for (uint32_t ib = i0; ib < i1; ib += 256u) {           // uniform trip count: every lane stays for the wave-wide counting
+    for (uint32_t ib = i0; ib < i1; ib += SEG_THREADS) {    // uniform trip count: every lane stays for the wave-wide counting
         const uint32_t i = ib + threadIdx.x;
         TRect r{ 0u, 0u, 0u, 0u, 1u, 0u };
         if (i < i1) {
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void k_preprocess(SRC src, uint32_t n, PU u, P
         count_buckets(h, tc.nb - 1u, (uint32_t)tc.tiles_x, r);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < tc.nb; b += 256u) tc.hist[(size_t)b * tc.rows + blockIdx.x] = h[b];       // one row per bucket: k_bucket_scan scans along the segments
+    for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) tc.hist[(size_t)b * tc.rows + blockIdx.x] = h[b];       // one row per bucket: k_bucket_scan scans along the segments
 }
 
 static PU make_pu(const Uniforms& un, int W, int H) {
@@ -340,8 +341,8 @@ static PU make_pu(const Uniforms& un, int W, int H) {
 template <class SRC>
 static hipError_t launch_pre(hipStream_t st, SRC src, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
     if (n == 0) return hipSuccess;
-    if (tc.hist) k_preprocess<SRC, true><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
-    else k_preprocess<SRC, false><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    if (tc.hist) k_project_count<SRC><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    else k_preprocess<SRC><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }
 hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src4D{ soa }, n, un, W, H, out, tc); }

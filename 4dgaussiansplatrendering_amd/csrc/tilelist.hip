@@ -81,11 +81,14 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict_
         }
         if (lane == 0) __hip_atomic_store(btot + b, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    // the bucket totals were stored write-through (agent-scope atomic stores) and are read back with agent-scope loads: all that is
+    // needed before the arrival counter is that this workgroup's stores have left (s_waitcnt) — no cache write-back, which would push
+    // out the XCD's whole L2 once per workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         const bool last = atomicAdd(&total[7], 1u) == gridDim.x - 1u;
-        if (last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); total[7] = 0u; }
+        if (last) total[7] = 0u;
         s_last = last ? 1u : 0u;
     }
     __syncthreads();
@@ -101,28 +104,27 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict_
     }
 }
 
-// Segment w again: every entry goes to tmp[bucket start + slot of run (w, bucket) + a counter in LDS].  256 threads, one record each per round.
-__global__ __launch_bounds__(256) void k_bucket_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t n, uint32_t seg, uint32_t nb,
+// Segment w again: every entry goes to tmp[bucket start + slot of run (w, bucket) + a counter in LDS].  SEG_THREADS threads, one record each per round.
+__global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t n, uint32_t seg, uint32_t nb,
                                                         const uint32_t* __restrict__ offs, const uint32_t* __restrict__ bbase, const uint32_t* __restrict__ total, uint2* __restrict__ tmp,
                                                         uint32_t tiles_x, uint32_t shard_rank, uint32_t shard_world) {
     __shared__ uint32_t cur[1024];
     if (total[1] & 1u) return;                             // aborted draw: slots would lie beyond the capacity
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    for (uint32_t b = tid; b < nb; b += 256u) cur[b] = bbase[b] + offs[(size_t)blockIdx.x * nb + b];
+    for (uint32_t b = tid; b < nb; b += SEG_THREADS) cur[b] = bbase[b] + offs[(size_t)blockIdx.x * nb + b];
     __syncthreads();
     const uint32_t nbm = nb - 1u, nbs = (uint32_t)__ffs((int)nb) - 1u;
     const uint32_t i0 = blockIdx.x * seg, i1 = min(n, i0 + seg);
-    for (uint32_t ib = i0; ib < i1; ib += 256u) {          // uniform trip count: every lane stays to the end
+    for (uint32_t ib = i0; ib < i1; ib += SEG_THREADS) {   // uniform trip count: every lane stays to the end
         const uint32_t i = ib + tid;
         TRect r{ 0u, 0u, 0u, 0u, 1u, 0u };
         uint32_t key = 0u;
         if (i < i1) { const uint2 rc = rects[i]; r = tile_rect(rc.x, rc.y, shard_rank, shard_world); if (r.count) key = skey[i]; }
         const bool big = r.count > 16u;
-        if (!big) for (uint32_t j = 0; j < r.count; ++j) {
-            const uint32_t t = tile_of(r, j, tiles_x);
+        if (!big) for_each_tile(r, tiles_x, [&](uint32_t t) {
             const uint32_t pos = atomicAdd(&cur[t & nbm], 1u);
             tmp[pos] = make_uint2(key, ((t >> nbs) << 24) | i);
-        }
+        });
         uint64_t m = __ballot(big);
         while (m) {                                        // large footprints: the whole wave writes one record's entries
             const int src = __ffsll((long long)m) - 1;
@@ -140,51 +142,59 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const uint2* __restrict_
     }
 }
 
-// Bucket b -> the lists of its tiles (tile = h * nb + b, h < 256): count per tile, scan, place.  A thread keeps up to 8 entries in
-// registers (all loads in flight at once); a bucket of up to 8192 entries is read once, a longer one in rounds of 8192, twice.
-constexpr int BT_THREADS = 1024, BT_ITEMS = 8;
-__global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles,
+// Bucket b -> the lists of its tiles (tile = h * nb + b, h < 256): count per list, scan, place.  A tile's list is kept as `slabs`
+// sub-lists by the top bits of the blend key (far slab first): counter = h * slabs + slab.  A thread keeps up to 8 entries in registers
+// (all loads in flight at once); a bucket of up to 8192 entries is read once, a longer one in rounds of 8192, twice.
+constexpr int BT_THREADS = 1024, BT_ITEMS = 8, BT_COUNTERS = 256 * (int)V2_MAX_SLABS;
+__global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift,
                                                              uint32_t* __restrict__ tstart, uint32_t* __restrict__ tcnt, uint2* __restrict__ entries,
                                                              uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t hint) {
-    __shared__ uint32_t cnt[256];
-    __shared__ uint32_t cur[256];
-    __shared__ uint32_t ws[4];
+    __shared__ uint32_t cnt[BT_COUNTERS];
+    __shared__ uint32_t ws[BT_THREADS / 64];
     if (total[1] & 1u) return;                             // capacity overflow (set by k_bucket_scan); bit 1 is raised HERE by other workgroups and must not stop this one
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
     const uint32_t lo = bbase[b], hi = bbase[b + 1];
+    const uint32_t nc = 256u * slabs, sl = (uint32_t)__ffs((int)slabs) - 1u;      // counters in use; log2(slabs)
     constexpr uint32_t ROUND = BT_THREADS * BT_ITEMS;
     const bool single = hi - lo <= ROUND;
-    if (tid < 256u) cnt[tid] = 0u;
+    for (uint32_t k = tid; k < nc; k += BT_THREADS) cnt[k] = 0u;
     __syncthreads();
+    auto counter_of = [&](const uint2& e) { return ((e.y >> 24) << sl) | min(slabs - 1u, e.x >> slab_shift); };
     uint2 e[BT_ITEMS];
     for (uint32_t r0 = lo; r0 < hi; r0 += ROUND) {
 #pragma unroll
         for (int j = 0; j < BT_ITEMS; ++j) { const uint32_t i = r0 + (uint32_t)j * BT_THREADS + tid; e[j] = i < hi ? tmp[i] : make_uint2(0u, 0xFFFFFFFFu); }
 #pragma unroll
-        for (int j = 0; j < BT_ITEMS; ++j) if (e[j].y != 0xFFFFFFFFu) atomicAdd(&cnt[e[j].y >> 24], 1u);
+        for (int j = 0; j < BT_ITEMS; ++j) if (e[j].y != 0xFFFFFFFFu) atomicAdd(&cnt[counter_of(e[j])], 1u);
     }
     __syncthreads();
-    uint32_t c = 0, inc = 0;
-    if (tid < 256u) {
-        c = cnt[tid]; inc = c;
+    // exclusive scan of the nc counters (4 per thread at most), the tile table, the longest list
+    constexpr int CPT = BT_COUNTERS / BT_THREADS;
+    uint32_t c[CPT], sum = 0, mx = 0;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
-        if (lane == 63u) ws[w] = inc;
-    }
+    for (int k = 0; k < CPT; ++k) { const uint32_t q = tid * CPT + k; c[k] = q < nc ? cnt[q] : 0u; sum += c[k]; mx = max(mx, c[k]); }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
+    if (lane == 63u) ws[w] = inc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
     __syncthreads();
-    if (tid < 256u) {
-        uint32_t base = 0;
+    uint32_t base = 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) if ((unsigned)k < w) base += ws[k];
-        const uint32_t first = lo + base + inc - c;
-        cur[tid] = first;
-        const uint32_t tile = tid * nb + b;
-        if (tile < ntiles) { tstart[tile] = first; tcnt[tile] = c; }
-        uint32_t mx = c;
+    for (int k = 0; k < BT_THREADS / 64; ++k) if ((unsigned)k < w) base += ws[k];
+    uint32_t run = lo + base + inc - sum;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
-        if (lane == 0u && mx) { atomicMax(&total[4], mx); if (mx > hint) atomicOr(&total[1], 2u); }
+    for (int k = 0; k < CPT; ++k) {
+        const uint32_t q = tid * CPT + k;
+        if (q < nc) {
+            cnt[q] = run;                                  // from here on: the list's running position
+            const uint32_t tile = (q >> sl) * nb + b;
+            if (tile < ntiles) { tstart[(size_t)tile * slabs + (q & (slabs - 1u))] = run; tcnt[(size_t)tile * slabs + (q & (slabs - 1u))] = c[k]; }
+            run += c[k];
+        }
     }
+    if (lane == 0u && mx) { atomicMax(&total[4], mx); if (mx > hint) atomicOr(&total[1], 2u); }
     __syncthreads();
     for (uint32_t r0 = lo; r0 < hi; r0 += ROUND) {
         if (!single) {
@@ -193,16 +203,17 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
         }
 #pragma unroll
         for (int j = 0; j < BT_ITEMS; ++j) if (e[j].y != 0xFFFFFFFFu) {
-            const uint32_t pos = atomicAdd(&cur[e[j].y >> 24], 1u);
+            const uint32_t pos = atomicAdd(&cnt[counter_of(e[j])], 1u);
             entries[pos] = make_uint2(e[j].x, e[j].y & 0x00FFFFFFu);
         }
     }
-    // the last workgroup to finish reports to the host (pinned, mapped memory behind the lane's event)
+    // The last workgroup to finish reports to the host (pinned, mapped memory behind the lane's event).  The longest-list maximum and the
+    // flag are device-scope atomics (they execute at the memory side): once this workgroup's have been acknowledged (s_waitcnt) it may
+    // count itself in — no cache write-back.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         if (atomicAdd(&total[6], 1u) == gridDim.x - 1u) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             const uint32_t flags = __hip_atomic_load(&total[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t longest = __hip_atomic_load(&total[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = longest; total_host[1] = flags;
@@ -210,15 +221,20 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
     }
 }
 
-bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords) {
+bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits) {
     if (nrecords == 0 || nrecords > V2_MAX_RECORDS) return false;
     uint32_t nb = 64;
     while ((size_t)nb * 256 < ntiles && nb < 1024) nb *= 2;
     if ((size_t)nb * 256 < ntiles) return false;
-    size_t rows = std::min<size_t>((nrecords + 1023) / 1024, 1024);
-    size_t seg = ((nrecords + rows - 1) / rows + 255) / 256 * 256;
+    // segments of >= 4096 records (longer runs per bucket, a small count matrix), at most 1024 of them (k_bucket_scan keeps a bucket's counts in registers)
+    size_t rows = std::min<size_t>((nrecords + 4095) / 4096, 1024);
+    size_t seg = ((nrecords + rows - 1) / rows + SEG_THREADS - 1) / SEG_THREADS * SEG_THREADS;
     rows = (nrecords + seg - 1) / seg;
-    t.nb = nb; t.rows = (uint32_t)rows; t.seg = (uint32_t)seg;
+    if (slabs < 1) slabs = 1;
+    if (slabs > V2_MAX_SLABS) slabs = V2_MAX_SLABS;
+    int sl = 0; while ((1u << sl) < slabs) ++sl;
+    if (keybits < sl) return false;
+    t.nb = nb; t.rows = (uint32_t)rows; t.seg = (uint32_t)seg; t.slabs = 1u << sl; t.slab_shift = (uint32_t)(keybits - sl);
     return true;
 }
 
@@ -235,8 +251,8 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
         if (t.bbase) { (void)hipStreamSynchronize(st); (void)hipFree(t.bbase); }
         t.bbase = t.btot = t.tstart = t.tcnt = nullptr;
         const size_t nt = std::max(ntiles, t.tiles_cap), nbc = std::max<size_t>(t.nb, t.nb_cap);
-        if ((e = hipMalloc(&t.bbase, (2 * nbc + 1 + 2 * nt) * 4)) != hipSuccess) return e;
-        t.btot = t.bbase + nbc + 1; t.tstart = t.btot + nbc; t.tcnt = t.tstart + nt;
+        if ((e = hipMalloc(&t.bbase, (2 * nbc + 1 + 2 * nt * V2_MAX_SLABS) * 4)) != hipSuccess) return e;     // the tile table holds V2_MAX_SLABS sub-lists per tile
+        t.btot = t.bbase + nbc + 1; t.tstart = t.btot + nbc; t.tcnt = t.tstart + nt * V2_MAX_SLABS;
         t.tiles_cap = nt; t.nb_cap = nbc;
     }
     if (t.skey_cap < nrecords) {
@@ -261,12 +277,12 @@ hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uin
 }
 
 hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
-    k_bucket_scatter<<<dim3(t.rows), dim3(256), 0, st>>>(rects, t.skey, (uint32_t)nrecords, t.seg, t.nb, t.hist + t.hist_cap, t.bbase, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
+    k_bucket_scatter<<<dim3(t.rows), dim3(SEG_THREADS), 0, st>>>(rects, t.skey, (uint32_t)nrecords, t.seg, t.nb, t.hist + t.hist_cap, t.bbase, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
     return hipGetLastError();
 }
 
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, const uint2* tmp, uint2* entries, uint32_t hint) {
-    k_bucket_tiles<<<dim3(t.nb), dim3(BT_THREADS), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.tstart, t.tcnt, entries, total, total_host, hint);
+    k_bucket_tiles<<<dim3(t.nb), dim3(BT_THREADS), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, t.tstart, t.tcnt, entries, total, total_host, hint);
     return hipGetLastError();
 }
 

@@ -94,31 +94,34 @@ def test_equal_depth_keys_blend_in_index_order(gs4d, oracle, monkeypatch):
     assert linf(other, eimg) > 1e-2
 
 
-def test_long_lists_grow_the_compositor_and_then_fall_back(gs4d, oracle, monkeypatch):
-    """Hundreds, then thousands, of splats on the same pixels: the tile scan reports the longest list, the draw is re-run with a larger
-    LDS list capacity, and beyond the largest one (2048 entries) on the instance-ordered path — every time the same picture."""
+def test_long_lists_grow_the_compositor_then_depth_slabs_then_fall_back(gs4d, oracle, monkeypatch):
+    """Hundreds, then thousands, of splats on the same pixels.  The list-building kernels report the longest list; the draw is re-run with
+    a larger LDS list capacity in the compositor, then with the lists cut into depth slabs, and — when slabs cannot help because the
+    keys are all equal — on the instance-ordered path.  Every time the same picture."""
     W, H = 256, 256
     cam = ((0.0, 0.0, 60.0), (0.0, 0.0, -1.0))
     view, proj = cam_mats(gs4d, cam, W, H)
     ctx = _ctx(gs4d, W, H, monkeypatch)
     seen = []
-    for n in (700, 700, 5000, 120):
+    for n, spread in ((700, 0.1), (700, 0.1), (5000, 0.1), (3000, 0.0), (120, 0.1)):
         pos, q, sc, rgba = scenes.cube_params(n, seed=50 + n)
         rgba[:, 3] *= 0.05
-        pos[:, 0:2] = 0.0                                                     # all on the view axis: one spot of the image, distinct depths
-        rec = gs4d.build_records_3d(pos * 0.1, q, sc * 1.5, rgba)
+        pos[:, 0:2] = 0.0                                                     # all on the view axis: one spot of the image; spread 0: one depth, equal keys
+        rec = gs4d.build_records_3d(pos * spread, q, sc * 1.5, rgba)
         img, perm, _, st = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
         eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
         assert np.array_equal(perm, eperm)
         assert linf(img, eimg) <= TOL
         assert np.abs(eimg - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.05
-        seen.append((st["unordered_draws"], st["reruns"], st["longest_list"]))
-    # frame 1: unordered, re-run once with a longer list capacity; frame 2: unordered, no re-run; frame 3: too long -> re-run ordered;
-    # frame 4: stays on the ordered path (it only probes the unordered one again after many frames)
-    assert seen[0][0] == 1 and seen[0][1] == 1 and 256 < seen[0][2] <= 700
-    assert seen[1][0] == 2 and seen[1][1] == 1
-    assert seen[2][1] == 2 and seen[2][2] > 2048
-    assert seen[3][0] == seen[2][0] and seen[3][1] == 2
+        seen.append(st)
+    # frame 1: unordered, re-run once with a longer list capacity; frame 2: unordered, no re-run
+    assert seen[0]["unordered_draws"] == 1 and seen[0]["reruns"] == 1 and 256 < seen[0]["longest_list"] <= 700
+    assert seen[1]["unordered_draws"] == 2 and seen[1]["reruns"] == 1
+    # frame 3: 5000 entries on a tile, distinct depths: cut into depth slabs, still unordered lists, every sub-list fits the compositor
+    assert seen[2]["unordered_draws"] == 3 and seen[2]["reruns"] > 1 and seen[2]["longest_list"] <= 2048 and seen[2]["tile_sort_passes"] == 0
+    # frame 4: 3000 entries with ONE key: no slab boundary separates them -> the instance-ordered path; frame 5 stays there
+    assert seen[3]["tile_sort_passes"] >= 2 and seen[3]["reruns"] > seen[2]["reruns"]
+    assert seen[4]["unordered_draws"] == seen[3]["unordered_draws"] and seen[4]["reruns"] == seen[3]["reruns"] and seen[4]["tile_sort_passes"] >= 2
     ctx.close()
 
 

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1; n=$2; steps=$3; lanes=${4:-1}
 export GS4D_LANES=$lanes
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kp_$tag -- python3 bench.py --splats $n --steps $steps --warmup 5 --no-cpu-baseline --no-stage-events > gpurun_out/${tag}_trace.log 2>&1 || { tail -5 gpurun_out/${tag}_trace.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kp_$tag -- python3 bench.py --splats $n --steps $steps --warmup 5 --no-cpu-baseline --no-stage-events --no-c3 --no-latency --windows 1 > gpurun_out/${tag}_trace.log 2>&1 || { tail -5 gpurun_out/${tag}_trace.log; exit 1; }
 cp $(ls gpurun_out/kp_$tag/*/*kernel_stats.csv | head -1) gpurun_out/${tag}_kstats.csv
 rm -rf gpurun_out/kp_$tag
 python3 - <<PY
