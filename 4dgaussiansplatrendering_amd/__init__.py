@@ -261,6 +261,53 @@ def parse_sd(path, object_scale=1.0, cap_records=1 << 22):
     return buf[:min(n, cap_records)].copy()
 
 
+class CameraState(C.Structure):
+    """gs4d_camera_state (include/gs4d.h): the Camera of Camera.h:16-85 as plain data."""
+    _fields_ = [("position", C.c_float * 3), ("orientation", C.c_float * 3), ("up", C.c_float * 3), ("width", C.c_int), ("height", C.c_int),
+                ("sensitivity", C.c_float), ("speed", C.c_float), ("fast_speed", C.c_float),
+                ("capture_mouse", C.c_int), ("first_capture", C.c_int), ("fix_view", C.c_int), ("fix_position", C.c_int), ("lock_x", C.c_int), ("lock_y", C.c_int)]
+
+    @classmethod
+    def make(cls, width, height, position, orientation, up=(0.0, 1.0, 0.0)):
+        st = cls()
+        st.position[:], st.orientation[:], st.up[:] = position, orientation, up
+        st.width, st.height = width, height
+        st.sensitivity, st.speed, st.fast_speed = 100.0, 0.5, 2.0          # Camera.h:78-80
+        st.first_capture = 1
+        return st
+
+
+class CameraInput(C.Structure):
+    _fields_ = [("keys", C.c_uint), ("mouse_x", C.c_double), ("mouse_y", C.c_double), ("imgui_active", C.c_int)]
+
+
+CAMKEY = {"W": 1, "S": 2, "A": 4, "D": 8, "E": 16, "Q": 32, "SPACE": 64, "LCTRL": 128, "LSHIFT": 256, "C": 512, "ESC": 1024}
+
+
+def camera_input(state, keys, mouse_x, mouse_y, imgui_active=False):
+    """One Camera::HandleInput call (Camera.cpp:116-183) on a CameraState; returns (recenter_cursor, hide_cursor)."""
+    inp = CameraInput(int(keys), float(mouse_x), float(mouse_y), 1 if imgui_active else 0)
+    rc, hide = C.c_int(0), C.c_int(0)
+    _lib.gs4d_host_camera_input(C.byref(state), C.byref(inp), C.byref(rc), C.byref(hide))
+    return bool(rc.value), bool(hide.value)
+
+
+def camera_look_at_point(state, point):
+    _lib.gs4d_host_camera_look_at_point(C.byref(state), _ptr(_f32(point)))
+
+
+def camera_viewport(width, height):
+    out = np.zeros(2, np.float32)
+    _lib.gs4d_host_camera_viewport(width, height, _ptr(out))
+    return out
+
+
+def camera_focal(fov, width, height):
+    out = np.zeros(2, np.float32)
+    _lib.gs4d_host_camera_focal(fov, width, height, _ptr(out))
+    return out
+
+
 def write_png(path, rgba8):
     """(H, W, 4) uint8 frame, bottom row first (the framebuffer's orientation) -> PNG file."""
     a = np.ascontiguousarray(rgba8, np.uint8)

@@ -78,9 +78,11 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
     // the tile's list is `slabs` sub-lists by the top bits of the key; larger key = nearer: the last slab is blended first
+    uint32_t my_start = 0u, my_cnt = 0u;                    // lane s: sub-list s of this tile (one load for the whole table row)
+    if (lane < slabs) { my_start = tstart[(size_t)tile * slabs + lane]; my_cnt = tcnt[(size_t)tile * slabs + lane]; }
     for (int sb = (int)slabs - 1; sb >= 0; --sb) {
-        const uint32_t start = tstart[(size_t)tile * slabs + sb];
-        const uint32_t E = min(tcnt[(size_t)tile * slabs + sb], (uint32_t)(64 * PER));       // k_bucket_tiles guarantees the bound; min() keeps a broken promise inside LDS
+        const uint32_t start = __shfl(my_start, sb, 64);
+        const uint32_t E = min((uint32_t)__shfl(my_cnt, sb, 64), (uint32_t)(64 * PER));         // k_bucket_tiles guarantees the bound; min() keeps a broken promise inside LDS
         if (E == 0u) continue;
         if (E > 1u) {
             WaveSort<PER> ws;

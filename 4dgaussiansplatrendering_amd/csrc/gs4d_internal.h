@@ -113,6 +113,7 @@ struct TileCount {                               // hist == nullptr: the ordered
     KeySrc ks;
 };
 constexpr uint32_t V2_MAX_LIST = 2048;           // longest list the compositor sorts in LDS.  Longer per-tile lists are cut into depth slabs (below); beyond V2_MAX_SLABS a draw uses the ordered path
+constexpr uint32_t V2_LIST_TARGET = 512;         // sub-list length the slab count aims for
 constexpr uint32_t V2_MAX_SLABS = 16;            // a tile's list is kept as `slabs` sub-lists by the top bits of the blend key: far slab first, each ordered by itself in the compositor
 constexpr int SEG_THREADS = 512;                 // workgroup size of the kernels that walk a segment of records (k_preprocess<.., true>, k_bucket_scatter)
 // list capacities the compositor is instantiated for (64 entries per lane-register): the smallest one >= n

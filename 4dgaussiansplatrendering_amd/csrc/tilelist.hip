@@ -115,28 +115,38 @@ __global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter(const uint2* __r
     __syncthreads();
     const uint32_t nbm = nb - 1u, nbs = (uint32_t)__ffs((int)nb) - 1u;
     const uint32_t i0 = blockIdx.x * seg, i1 = min(n, i0 + seg);
-    for (uint32_t ib = i0; ib < i1; ib += SEG_THREADS) {   // uniform trip count: every lane stays to the end
-        const uint32_t i = ib + tid;
-        TRect r{ 0u, 0u, 0u, 0u, 1u, 0u };
-        uint32_t key = 0u;
-        if (i < i1) { const uint2 rc = rects[i]; r = tile_rect(rc.x, rc.y, shard_rank, shard_world); if (r.count) key = skey[i]; }
-        const bool big = r.count > 16u;
-        if (!big) for_each_tile(r, tiles_x, [&](uint32_t t) {
-            const uint32_t pos = atomicAdd(&cur[t & nbm], 1u);
-            tmp[pos] = make_uint2(key, ((t >> nbs) << 24) | i);
-        });
-        uint64_t m = __ballot(big);
-        while (m) {                                        // large footprints: the whole wave writes one record's entries
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            TRect rr;
-            rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
-            rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
-            const uint32_t key2 = __shfl(key, src, 64), rec2 = __shfl(i, src, 64);
-            for (uint32_t j = lane; j < rr.count; j += 64u) {
-                const uint32_t t = tile_of(rr, j, tiles_x);
+    constexpr int SC_ITEMS = 4;                            // records per thread and round: all their loads are in flight before the first LDS atomic
+    for (uint32_t ib = i0; ib < i1; ib += SEG_THREADS * SC_ITEMS) {      // uniform trip count: every lane stays to the end
+        uint2 rc[SC_ITEMS]; uint32_t kk[SC_ITEMS];
+#pragma unroll
+        for (int q = 0; q < SC_ITEMS; ++q) {
+            const uint32_t i = ib + (uint32_t)q * SEG_THREADS + tid;
+            rc[q] = i < i1 ? rects[i] : make_uint2(1u, 0u);
+            kk[q] = i < i1 ? skey[i] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < SC_ITEMS; ++q) {
+            const uint32_t i = ib + (uint32_t)q * SEG_THREADS + tid;
+            const TRect r = tile_rect(rc[q].x, rc[q].y, shard_rank, shard_world);
+            const uint32_t key = kk[q];
+            const bool big = r.count > 16u;
+            if (!big) for_each_tile(r, tiles_x, [&](uint32_t t) {
                 const uint32_t pos = atomicAdd(&cur[t & nbm], 1u);
-                tmp[pos] = make_uint2(key2, ((t >> nbs) << 24) | rec2);
+                tmp[pos] = make_uint2(key, ((t >> nbs) << 24) | i);
+            });
+            uint64_t m = __ballot(big);
+            while (m) {                                    // large footprints: the whole wave writes one record's entries
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                TRect rr;
+                rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
+                rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
+                const uint32_t key2 = __shfl(key, src, 64), rec2 = __shfl(i, src, 64);
+                for (uint32_t j = lane; j < rr.count; j += 64u) {
+                    const uint32_t t = tile_of(rr, j, tiles_x);
+                    const uint32_t pos = atomicAdd(&cur[t & nbm], 1u);
+                    tmp[pos] = make_uint2(key2, ((t >> nbs) << 24) | rec2);
+                }
             }
         }
     }
@@ -223,8 +233,9 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
 
 bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits) {
     if (nrecords == 0 || nrecords > V2_MAX_RECORDS) return false;
+    // buckets: enough that tile / nb < 256, and about 8192 entries each (k_bucket_tiles reads a bucket of that size once) at ~1.4 entries per record
     uint32_t nb = 64;
-    while ((size_t)nb * 256 < ntiles && nb < 1024) nb *= 2;
+    while (((size_t)nb * 256 < ntiles || (size_t)nb * 8192 < nrecords + nrecords / 2) && nb < 1024) nb *= 2;
     if ((size_t)nb * 256 < ntiles) return false;
     // segments of >= 4096 records (longer runs per bucket, a small count matrix), at most 1024 of them (k_bucket_scan keeps a bucket's counts in registers)
     size_t rows = std::min<size_t>((nrecords + 4095) / 4096, 1024);

@@ -426,6 +426,61 @@ int main(int argc, char** argv) {
         dump("gaussians2d_in", "f32", in2.data(), in2.size(), 8);
         dump("gaussians2d_records", "f32", out2.data(), out2.size(), 12);
     }
+    // (8) Camera input model.  Camera::HandleInput / HandleCamRotation (Camera.cpp:116-207) call GLFW, whose library is absent here, so the
+    //     key/cursor plumbing is restated below (the statements of Camera.cpp in their order, keys and cursor taken from a table); every
+    //     arithmetic step is the reference's: glm::rotate(vec3, angle, axis), glm::normalize, glm::cross, glm::radians on the Camera's
+    //     own public members, and GetViewport / GetFocal / SetIsViewFixedOnPoint run from the reference's Camera.cpp itself.
+    {
+        const int W = 800, H = 800;
+        Camera cam(W, H, glm::vec3(60, 90, 90), glm::vec3(0, -1, -1));
+        const float mSensitivity = 100.0f, mSpeed = 0.5f, mFastSpeed = 2.0f;      // Camera.h:78-80
+        bool capture = false;
+        enum { KW = 1, KS = 2, KA = 4, KD = 8, KE = 16, KQ = 32, KSPACE = 64, KCTRL = 128, KSHIFT = 256, KC = 512, KESC = 1024 };
+        std::vector<float> in, out;
+        for (int step = 0; step < 96; ++step) {
+            unsigned keys = 0;
+            const float r = urand(0.0f, 1.0f);
+            if (step == 3) keys |= KC;                                    // capture the mouse early ...
+            if (step == 70) keys |= KESC;                                 // ... release it late
+            if (step == 80) keys |= KC;
+            for (int b = 0; b < 9; ++b) if (urand(0.0f, 1.0f) < 0.3f) keys |= 1u << b;
+            (void)r;
+            const double mx = (double)W / 2.0 + (double)(int)urand(-40.0f, 40.0f), my = (double)H / 2.0 + (double)(int)urand(-30.0f, 30.0f);
+            // --- Camera.cpp:116-183 ---
+            float currentSpeed = mSpeed;
+            if (keys & KSHIFT) currentSpeed = mFastSpeed;
+            if (keys & KW) cam.position += cam.orientation * currentSpeed;
+            if (keys & KS) cam.position += cam.orientation * -currentSpeed;
+            if (keys & KA) cam.position += -currentSpeed * glm::normalize(glm::cross(cam.orientation, cam.up));
+            if (keys & KD) cam.position += currentSpeed * glm::normalize(glm::cross(cam.orientation, cam.up));
+            if (keys & KE) cam.up = glm::rotate(cam.up, glm::radians(1.0f), cam.orientation);
+            if (keys & KQ) cam.up = glm::rotate(cam.up, glm::radians(-1.0f), cam.orientation);
+            if (keys & KSPACE) cam.position += currentSpeed * cam.up;
+            if (keys & KCTRL) cam.position += -currentSpeed * cam.up;
+            double mouseX = mx, mouseY = my;
+            if ((keys & KC) && !capture) { mouseX = (double)W / 2.0; mouseY = (double)H / 2.0; capture = true; }      // glfwSetCursorPos(centre)
+            if (keys & KESC) capture = false;
+            if (capture) {                                                 // --- Camera.cpp:191-207 ---
+                double rotX = -mSensitivity * (mouseY - int((double)H / 2.0)) / (double)(H);
+                double rotY = -mSensitivity * (mouseX - int((double)W / 2.0)) / (double)(W);
+                cam.orientation = glm::rotate(cam.orientation, (float)glm::radians(rotX), glm::normalize(glm::cross(cam.orientation, cam.up)));
+                glm::vec3 side = glm::normalize(glm::cross(cam.up, cam.orientation));
+                cam.up = glm::normalize(glm::cross(cam.orientation, side));
+                cam.orientation = glm::rotate(cam.orientation, (float)glm::radians(rotY), cam.up);
+            }
+            const float irow[3] = { (float)keys, (float)mx, (float)my };
+            in.insert(in.end(), irow, irow + 3);
+            const float orow[10] = { cam.position.x, cam.position.y, cam.position.z, cam.orientation.x, cam.orientation.y, cam.orientation.z, cam.up.x, cam.up.y, cam.up.z, capture ? 1.0f : 0.0f };
+            out.insert(out.end(), orow, orow + 10);
+        }
+        dump("camera_walk_in", "f32", in.data(), in.size(), 3);
+        dump("camera_walk_out", "f32", out.data(), out.size(), 10);
+        // the reference's own Camera.cpp for the three helpers that need no window
+        cam.SetIsViewFixedOnPoint(true, glm::vec4(1.0f, 2.0f, 3.0f, 1.0f));
+        const glm::vec2 vpn = cam.GetViewport(), foc = cam.GetFocal();
+        const float misc[10] = { cam.orientation.x, cam.orientation.y, cam.orientation.z, cam.up.x, cam.up.y, cam.up.z, vpn.x, vpn.y, foc.x, foc.y };
+        dump("camera_misc", "f32", misc, 10, 10);
+    }
     fprintf(g_manifest, "\n}\n"); fclose(g_manifest);
     printf("refgen: fixtures written to %s\n", g_out.c_str());
     return 0;

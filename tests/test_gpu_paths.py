@@ -114,11 +114,11 @@ def test_long_lists_grow_the_compositor_then_depth_slabs_then_fall_back(gs4d, or
         assert linf(img, eimg) <= TOL
         assert np.abs(eimg - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.05
         seen.append(st)
-    # frame 1: unordered, re-run once with a longer list capacity; frame 2: unordered, no re-run
-    assert seen[0]["unordered_draws"] == 1 and seen[0]["reruns"] == 1 and 256 < seen[0]["longest_list"] <= 700
-    assert seen[1]["unordered_draws"] == 2 and seen[1]["reruns"] == 1
+    # frame 1: unordered, re-run with depth slabs and / or a longer list capacity; frame 2: unordered, no re-run
+    assert seen[0]["unordered_draws"] == 1 and seen[0]["reruns"] >= 1 and seen[0]["longest_list"] <= 700 and seen[0]["tile_sort_passes"] == 0
+    assert seen[1]["unordered_draws"] == 2 and seen[1]["reruns"] == seen[0]["reruns"]
     # frame 3: 5000 entries on a tile, distinct depths: cut into depth slabs, still unordered lists, every sub-list fits the compositor
-    assert seen[2]["unordered_draws"] == 3 and seen[2]["reruns"] > 1 and seen[2]["longest_list"] <= 2048 and seen[2]["tile_sort_passes"] == 0
+    assert seen[2]["unordered_draws"] == 3 and seen[2]["reruns"] > seen[1]["reruns"] and seen[2]["longest_list"] <= 2048 and seen[2]["tile_sort_passes"] == 0
     # frame 4: 3000 entries with ONE key: no slab boundary separates them -> the instance-ordered path; frame 5 stays there
     assert seen[3]["tile_sort_passes"] >= 2 and seen[3]["reruns"] > seen[2]["reruns"]
     assert seen[4]["unordered_draws"] == seen[3]["unordered_draws"] and seen[4]["reruns"] == seen[3]["reruns"] and seen[4]["tile_sort_passes"] >= 2

@@ -151,3 +151,32 @@ def test_png_writer(gs4d, tmp_path):
     assert np.array_equal(rows[:, 1:].reshape(h, w, 4), img[::-1])
     with pytest.raises(OSError):
         gs4d.write_png(str(tmp_path / "no_such_dir" / "f.png"), img)
+
+
+def test_camera_input_model_bit_for_bit(gs4d, oracle):
+    """Camera::HandleInput / HandleCamRotation (Camera.cpp:116-207) as a state machine: 96 steps of keys + cursor positions give the very
+    positions, orientations and up vectors GLM gave the fixture generator (glm::rotate / normalize / cross on the reference's Camera;
+    the GLFW plumbing around them is restated there, see oracle/ref/refgen.cpp section 8)."""
+    steps = oracle.golden("camera_walk_in")
+    want = oracle.golden("camera_walk_out")
+    st = gs4d.CameraState.make(800, 800, (60, 90, 90), (0, -1, -1))
+    captured_before = False
+    for (keys, mx, my), row in zip(steps, want):
+        recenter, hide = gs4d.camera_input(st, int(keys), mx, my)
+        got = np.array(list(st.position) + list(st.orientation) + list(st.up), np.float32)
+        assert np.array_equal(got.view(np.uint32), row[:9].view(np.uint32)), (keys, got, row)
+        assert bool(st.capture_mouse) == bool(row[9])
+        assert hide == ((int(keys) & gs4d.CAMKEY["C"]) != 0 and not captured_before)
+        assert recenter == bool(st.capture_mouse) or hide
+        captured_before = bool(st.capture_mouse)
+    # imgui_active: nothing moves (Camera.cpp:119)
+    before = bytes(st)
+    gs4d.camera_input(st, 0x7FF, 10.0, 10.0, imgui_active=True)
+    assert bytes(st) == before
+    # SetIsViewFixedOnPoint / GetViewport / GetFocal run from the reference's own Camera.cpp in the generator
+    misc = oracle.golden("camera_misc").reshape(-1)
+    gs4d.camera_look_at_point(st, (1.0, 2.0, 3.0))
+    got = np.array(list(st.orientation) + list(st.up), np.float32)
+    assert np.array_equal(got.view(np.uint32), misc[:6].view(np.uint32))
+    assert np.array_equal(gs4d.camera_viewport(800, 800).view(np.uint32), misc[6:8].view(np.uint32))
+    assert np.array_equal(gs4d.camera_focal(60.0, 800, 800).view(np.uint32), misc[8:10].view(np.uint32))
