@@ -5,6 +5,10 @@
 // loop can be replaced by the GPU key generation (--gpu-keys).  Writes the RGBA32F framebuffer to a file for the parity test.
 //
 //   scene_replay <teapot_vdata.bin> <out.rgba32f> <width> <height> <time> [--gpu-keys] [--no-sort]
+//   scene_replay <teapot_vdata.bin> <out.rgba32f> <width> <height> <time> --frames N --png <prefix> [--keys WASDEQ...] [--dt step]
+// The second form is the frame loop of Application.cpp:145-190 without a window: per iteration Clear, Camera::HandleInput (from a
+// scripted key table), blend state, Update (time += dt), Render; frame k-1 is presented — packed to RGBA8 on the device and written as
+// <prefix>_%04d.png — after frame k has been queued, as a swap chain does.  <out.rgba32f> receives the last frame.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -96,7 +100,15 @@ int main(int argc, char** argv) {
     const int W = std::atoi(argv[3]), H = std::atoi(argv[4]);
     const float t = (float)std::atof(argv[5]);
     bool gpu_keys = false, do_sort = true;
-    for (int i = 6; i < argc; ++i) { if (!std::strcmp(argv[i], "--gpu-keys")) gpu_keys = true; if (!std::strcmp(argv[i], "--no-sort")) do_sort = false; }
+    int frames = 1; const char* png = nullptr; const char* keys = ""; float dt = 0.25f;      // Scenes.h:187 m_time_speed
+    for (int i = 6; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--gpu-keys")) gpu_keys = true;
+        if (!std::strcmp(argv[i], "--no-sort")) do_sort = false;
+        if (!std::strcmp(argv[i], "--frames") && i + 1 < argc) frames = std::atoi(argv[++i]);
+        if (!std::strcmp(argv[i], "--png") && i + 1 < argc) png = argv[++i];
+        if (!std::strcmp(argv[i], "--keys") && i + 1 < argc) keys = argv[++i];
+        if (!std::strcmp(argv[i], "--dt") && i + 1 < argc) dt = (float)std::atof(argv[++i]);
+    }
     std::vector<float> model;
     { FILE* f = std::fopen(argv[1], "rb"); if (!f) { std::perror(argv[1]); return 1; } float v; while (std::fread(&v, 4, 1, f) == 1) model.push_back(v); std::fclose(f); }
     gs4d_ctx* ctx = nullptr;
@@ -111,9 +123,34 @@ int main(int argc, char** argv) {
             LinearMotion scene(renderer, cam, model);
             scene.init();
             scene.m_time = t; scene.m_do_sort = do_sort; scene.m_gpu_keys = gpu_keys;
-            renderer.Clear();
-            glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA);
-            scene.Render();
+            GLFWwindow window;                                                     // input state only
+            for (const char* k = keys; *k; ++k) { const int code = *k == '_' ? GLFW_KEY_SPACE : (*k >= 'a' && *k <= 'z') ? *k - 32 : *k; if (code >= 0 && code < 512) window.keys[code] = 1; }
+            // the presentation buffer is a library buffer: its device pointer is what the pack kernel writes, gs4d_buffer_read brings it back
+            void* dev8 = nullptr; std::vector<uint8_t> host8; gs4d_buf pbuf = 0;
+            if (png) {
+                gs4d::compat::Check(gs4d_buffer_create(ctx, nullptr, (size_t)W * H * 4, &pbuf), "gs4d_buffer_create");
+                size_t nb = 0; gs4d::compat::Check(gs4d_buffer_device_ptr(ctx, pbuf, &dev8, &nb), "gs4d_buffer_device_ptr");
+                host8.resize((size_t)W * H * 4);
+            }
+            auto present = [&](int frames_back, int index) {
+                // RGBA8 pack on the device behind the frame's own compositing kernel, then a copy the host waits for: the next frame is already queued
+                gs4d::compat::Check(gs4d_read_frame_rgba8_device(ctx, frames_back, dev8, (size_t)W * H * 4), "gs4d_read_frame_rgba8_device");
+                gs4d::compat::Check(gs4d_finish(ctx), "gs4d_finish");
+                gs4d::compat::Check(gs4d_buffer_read(ctx, pbuf, 0, host8.data(), host8.size()), "gs4d_buffer_read");
+                char name[512]; std::snprintf(name, sizeof name, "%s_%04d.png", png, index);
+                if (gs4d_host_write_png(name, host8.data(), W, H) != 0) throw std::runtime_error(std::string("cannot write ") + name);
+            };
+            for (int f = 0; f < frames; ++f) {                                     // Application.cpp:145-190
+                renderer.Clear();
+                cam.HandleInput(&window);
+                glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA);
+                glEnable(GL_BLEND); glDisable(GL_DEPTH_TEST);
+                if (f > 0) scene.m_time += dt;                                     // Update(): m_time += m_time_speed (Scenes.h:346)
+                scene.Render();
+                if (png && f > 0) present(1, f - 1);                               // the previous image of the swap chain
+            }
+            if (png) present(0, frames - 1);
+            if (pbuf) gs4d_buffer_destroy(ctx, pbuf);
             std::vector<float> img((size_t)W * H * 4);
             gs4d::compat::Check(gs4d_read_pixels(ctx, img.data(), img.size() * 4), "gs4d_read_pixels");
             FILE* f = std::fopen(argv[2], "wb"); if (!f) { std::perror(argv[2]); return 1; }

@@ -143,7 +143,7 @@ def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file):
             "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
 
 
-def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None):
+def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None, keybufs=2):
     """One GPU, static 3D splats in the cube (configs[1] / configs[2]).  Returns (result dict, records)."""
     cam = scenes.CAM_CUBE
     view = gs4d.look_at(cam[0], cam[1])
@@ -151,7 +151,7 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
     pos, q, scale, rgba = scenes.cube_params(n)
     rec = gs4d.build_records_3d(pos, q, scale, rgba)
     del pos, q, scale, rgba
-    sc = Scene(gs4d, rec, cam, view, proj, device, lanes=lanes)
+    sc = Scene(gs4d, rec, cam, view, proj, device, lanes=lanes, keybufs=keybufs)
     ctx = sc.ctx
 
     def fence():
@@ -188,6 +188,8 @@ def main():
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the line reports the median window")
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: frames of every rank per RCCL gather")
+    ap.add_argument("--lanes", type=int, default=None, help="frame lanes of the context (default: the library's, 2); experiments")
+    ap.add_argument("--keybufs", type=int, default=None, help="key / sort-index buffer pairs the application cycles through (default: one per lane)")
     ap.add_argument("--no-c3", action="store_true", help="N=1: skip the configs[2] block (10^7 splats)")
     ap.add_argument("--no-latency", action="store_true", help="N=1: skip the one-lane frame time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -218,7 +220,8 @@ def main():
 
 def single_gpu(args, gs4d, scenes, device):
     n = args.splats
-    res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events)
+    kb = args.keybufs or args.lanes or 2
+    res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
     tfile = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{'c2' if n == 1_000_000 else 'c3' if n == 10_000_000 else 'x'}.json")
     roofline = roofline_block(res["stats"], res["stage_ms"], res["warm_ms"], n, res["ms_per_step"], tfile)
     latency = None
@@ -228,7 +231,7 @@ def single_gpu(args, gs4d, scenes, device):
     c3 = None
     if not args.no_c3 and n == 1_000_000:
         n3 = 10_000_000
-        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 5, 3, device, stage_events=not args.no_stage_events)
+        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 5, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
         c3 = {"workload": "10,000,000 random 3D splats in a 400^3 cube, single 1080p frame (BASELINE.json configs[2])", "splats": n3,
               "ms_per_step": r3["ms_per_step"], "value": r3["value"], "unit": "splats/s", "windows_ms_per_step": r3["windows_ms_per_step"],
               "tile_list_entries": r3["stats"]["entries"], "longest_tile_list": r3["stats"]["longest_list"], "unordered_draws": r3["stats"]["unordered_draws"],

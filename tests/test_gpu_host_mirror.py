@@ -31,3 +31,43 @@ def test_linear_motion_scene_through_the_mirrored_classes(gs4d, oracle, tmp_path
     err = float(np.abs(img.astype(np.float64) - eimg).max())
     assert err <= 1e-4, err
     assert np.abs(eimg - oracle.CLEAR).max() > 0.3
+
+
+def test_frame_loop_with_camera_input_and_png_dump(gs4d, oracle, tmp_path):
+    """Application.cpp:145-190 as host/scene_replay.cpp runs it without a window: Clear, Camera::HandleInput (W held down: the camera
+    advances 0.5 * orientation per frame, Camera.cpp:131-134), Update (time += 0.25), Render; every frame is presented as a PNG from the
+    swap chain's previous image.  The last frame must be the checker's picture for the camera and time the loop arrived at."""
+    import struct
+    import zlib
+    W, H, t0, frames = 640, 360, 10.0, 3
+    out = str(tmp_path / "last.bin")
+    prefix = str(tmp_path / "frame")
+    r = subprocess.run([EXE, os.path.join(oracle.GOLDEN_DIR, "teapot_vdata.bin"), out, str(W), str(H), str(t0), "--gpu-keys", "--frames", str(frames), "--png", prefix, "--keys", "W"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cam_pos = np.array(scenes.CAM_TEAPOT[0], np.float32)
+    ori = np.array(scenes.CAM_TEAPOT[1], np.float32)
+    for _ in range(frames):
+        cam_pos = cam_pos + ori * np.float32(0.5)
+    t = t0 + 0.25 * (frames - 1)
+    rec = gs4d.scene_linear(oracle.golden("teapot_vdata"))
+    view = oracle.look_at(tuple(cam_pos), tuple(ori))
+    proj = oracle.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
+    eimg, _, _ = oracle.render_4d(rec, True, t, 0.0, tuple(cam_pos), view, proj, W, H, nthreads=16)
+    img = np.fromfile(out, np.float32).reshape(H, W, 4)
+    assert float(np.abs(img.astype(np.float64) - eimg).max()) <= 1e-4
+    # the PNGs: one per frame, the last one is the last frame in the window's format (RGBA8, top row first)
+    for k in range(frames):
+        data = open(f"{prefix}_{k:04d}.png", "rb").read()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", data[16:24]) == (W, H)
+    raw, pos = b"", 8
+    while pos < len(data):
+        ln, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        if typ == b"IDAT":
+            raw += data[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+    px = np.frombuffer(zlib.decompress(raw), np.uint8).reshape(H, 1 + W * 4)
+    assert not px[:, 0].any()                                  # filter type 0 on every row (gs4d_host_write_png)
+    png = px[:, 1:].reshape(H, W, 4)[::-1]                     # bottom row first, like the framebuffer
+    want = np.rint(np.clip(eimg, 0.0, 1.0) * 255.0)
+    assert np.abs(png.astype(np.int32) - want.astype(np.int32)).max() <= 1
