@@ -19,9 +19,11 @@ __device__ __forceinline__ void blend_fragment(float u, float v, float alpha, fl
     const float q = u * u + v * v;
     const float cg = __expf(-32.0f * q);
     if (cg >= 0.0001f) {                                   // Splat4DFragShader.GLSL:30 discard
-        const float al = alpha * cg;
+        // The reference blends into a fixed-point (RGBA8) framebuffer: the GL clamps the fragment's colour and alpha to [0, 1] before the
+        // blend (OpenGL 4.4, 17.3.8).  Colours that are not premultiplied were clamped once per record by the projection kernel.
+        const float al = __saturatef(alpha * cg);
         const float w = T * al;
-        if (PREMULT_C) { r_ *= cg; g_ *= cg; b_ *= cg; }   // Splat3DFragShaderFull.GLSL:22
+        if (PREMULT_C) { r_ = __saturatef(r_ * cg); g_ = __saturatef(g_ * cg); b_ = __saturatef(b_ * cg); }   // Splat3DFragShaderFull.GLSL:22
         Cr += w * r_; Cg += w * g_; Cb += w * b_; A += w * al;
         T *= (1.0f - al);
     }

@@ -792,6 +792,15 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
 // ---- draw ----
 static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     (void)hipSetDevice(c->device);
+    if (a.quads || a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT) {
+        // The quad set-up takes uProj * vec4(offset, 0, 1) + ps as "centre + (P00 * x, P11 * y)" at w = 1, which is what the shader computes
+        // for a matrix with glm::perspective's sparsity (Camera.cpp:55-58) — the only kind the reference produces.  Anything else is refused
+        // rather than drawn differently.
+        const float* P = a.u.proj;
+        const bool ok = P[1] == 0.0f && P[2] == 0.0f && P[3] == 0.0f && P[4] == 0.0f && P[6] == 0.0f && P[7] == 0.0f && P[8] == 0.0f && P[9] == 0.0f
+                     && P[12] == 0.0f && P[13] == 0.0f && P[15] == 0.0f && P[11] != 0.0f && P[0] != 0.0f && P[5] != 0.0f;
+        if (!ok) return fail(c, GS4D_E_UNSUPPORTED, "draw: uProj must have the sparsity of glm::perspective (P00, P11, P22, P23, P32 only)");
+    }
     // the lane's scratch still belongs to its previous draw, and the image this draw blends onto must be complete: validate those
     // (not the other lanes' draws: their frames are still in flight and nothing here depends on them)
     int rc = resolve_lane(c, c->cur); if (rc) return rc;
@@ -882,7 +891,7 @@ int gs4d_draw_lines(gs4d_ctx* c, const float* verts, size_t nverts, int dims, in
     HIPCHK(c, hipMemcpyAsync(L.line_verts, verts, floats * 4, hipMemcpyHostToDevice, L.s));     // the caller's array is reusable on return (pageable source)
     LineParams p;
     for (int i = 0; i < 16; ++i) p.vp[i] = viewproj ? viewproj[i] : (i % 5 == 0 ? 1.0f : 0.0f);
-    for (int i = 0; i < 4; ++i) p.rgba[i] = rgba[i];
+    for (int i = 0; i < 4; ++i) p.rgba[i] = std::min(std::max(rgba[i], 0.0f), 1.0f);      // the GL clamps fragment colours before blending into a fixed-point framebuffer
     p.W = c->W; p.H = c->H;
     HIPCHK(c, launch_lines(L.s, L.line_verts, nverts, dims, strip ? 1 : 0, p, width, F.linecnt, F.mem));
     ++c->ops;

@@ -109,7 +109,7 @@ __device__ __forceinline__ bool fin(float x) { return isfinite(x); }
 
 // Window-space set-up + record store.  ncx,ncy = NDC centre; kx,ky = NDC scale of the quad offset.
 __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid, const Quad& q, float ncx, float ncy, float kx, float ky,
-                                      int W, int H, float r, float g, float b, float alpha) {
+                                      int W, int H, float r, float g, float b, float alpha, bool clamp_rgb) {
     float cx = 0, cy = 0, a0x = 0, a0y = 0, a1x = 0, a1y = 0, hx = 0, hy = 0;
     uint32_t rect0 = 1u, rect1 = 0u;           // empty
     if (valid) {
@@ -138,6 +138,9 @@ __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid,
         }
     }
     if (!valid) { cx = cy = a0x = a0y = a1x = a1y = hx = hy = 0.0f; alpha = 0.0f; rect0 = 1u; rect1 = 0u; }
+    // the GL clamps a fragment's colour to [0, 1] before blending into the reference's RGBA8 framebuffer; where the fragment shader passes
+    // the colour through unchanged that is a per-record operation (the 3D-Full shader multiplies by c first: clamped per fragment)
+    if (clamp_rgb) { r = __saturatef(r); g = __saturatef(g); b = __saturatef(b); }
     out.rects[i] = make_uint2(rect0, rect1);
     float4* o = out.proj + (size_t)i * 4;
     o[0] = make_float4(cx, cy, a0x, a0y);
@@ -203,6 +206,8 @@ __device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float
     float bound = 1.2f * psw;
     if (z < 0.0f || z > 1.0f || psx < -bound || psx > bound || psy < -bound || psy > bound) return false;
     if (!(fin(psx) && fin(psy) && fin(z))) return false;
+    // gl_Position = uProj * vec4(R*S*v, 0, 1) + ps (:147): all four corners get z = ps.z + P[3][2] at w = 1, and the GL clips -w <= z <= w
+    { const float zq = psz + P[14]; if (zq < -1.0f || zq > 1.0f) return false; }
     float z2 = pcz * pcz;
     float J[3][3] = { { 1.0f / pcz, 0.0f, -pcx / z2 }, { 0.0f, 1.0f / pcz, -pcy / z2 }, { 0.0f, 0.0f, 0.0f } };
     float Wt[3][3];
@@ -261,7 +266,7 @@ __device__ __forceinline__ uint2 project_record(const Src4D& src, uint32_t n, ui
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, mx, my, mz, C, q, ncx, ncy);
     key = blend_key_4d(ks, i, pos, s3);
-    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w);
+    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w, true);
 }
 
 __device__ __forceinline__ uint2 project_record(const Src3D& src, uint32_t, uint32_t i, const PU& u, const PreOut& out, const KeySrc&, uint32_t& key) {
@@ -274,7 +279,7 @@ __device__ __forceinline__ uint2 project_record(const Src3D& src, uint32_t, uint
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, v[2], v[3], v[4], C, q, ncx, ncy);
     key = i;
-    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8]);
+    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8], false);
 }
 
 __device__ __forceinline__ uint2 project_record(const Src2D& src, uint32_t, uint32_t i, const PU& u, const PreOut& out, const KeySrc&, uint32_t& key) {
@@ -297,7 +302,7 @@ __device__ __forceinline__ uint2 project_record(const Src2D& src, uint32_t, uint
     bool valid = (clipw > 0.0f) && !(clipz < -clipw || clipz > clipw);
     float kx = P[0] / clipw, ky = P[5] / clipw;
     key = i;
-    return emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7]);
+    return emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7], true);
 }
 
 // One thread per record (the ordered path).

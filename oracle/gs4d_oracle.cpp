@@ -441,6 +441,9 @@ inline void project3d(gs4do_proj& o, V3 mean, const float C[3][3], const float V
     // NaN position produces no fragments anyway)
     if (z < 0.0f || z > 1.0f || ps.x < -bound || ps.x > bound || ps.y < -bound || ps.y > bound) { o.valid = 0; return; }
     if (!(std::isfinite(ps.x) && std::isfinite(ps.y) && std::isfinite(z))) { o.valid = 0; return; }
+    // gl_Position = uProj * vec4(R*S*v, 0, 1) + ps (Splat4DVertexShaderInstanced.GLSL:147): every corner has z = ps.z + uProj[3][2] at
+    // w = 1, and the fixed-function clipper keeps -w <= z <= w (OpenGL 4.4, 13.5) — the whole quad or nothing
+    { const float zq = ps.z + P[14]; if (zq < -1.0f || zq > 1.0f) { o.valid = 0; return; } }
     float z2 = pc.z * pc.z;
     // J columns (1/z, 0, -x/z2), (0, 1/z, -y/z2), (0,0,0)
     float J[3][3] = { { 1.0f / pc.z, 0.0f, -pc.x / z2 }, { 0.0f, 1.0f / pc.z, -pc.y / z2 }, { 0.0f, 0.0f, 0.0f } };
@@ -576,6 +579,8 @@ GS4DO_API void gs4do_composite(const gs4do_proj* proj, const uint32_t* order, si
                     float u, v, src[4];
                     if (!gs4do_covered(p, i, j, u, v)) continue;
                     if (!gs4do_fragment(p, frag_mode, u, v, src)) continue;
+                    // the reference's framebuffer is fixed-point (RGBA8): fragment colour and alpha are clamped to [0, 1] before the blend (OpenGL 4.4, 17.3.8)
+                    for (int q = 0; q < 4; ++q) src[q] = fminf(fmaxf(src[q], 0.0f), 1.0f);
                     float* d = rgba + 4 * ((size_t)j * W + i);
                     float a = src[3], ia = 1.0f - a;
                     d[0] = src[0] * a + d[0] * ia; d[1] = src[1] * a + d[1] * ia; d[2] = src[2] * a + d[2] * ia; d[3] = src[3] * a + d[3] * ia;
@@ -603,8 +608,9 @@ static bool clip_t(float num, float den, float& t0, float& t1) {
 GS4DO_API void gs4do_draw_lines(float* rgba, int W, int H, const float* verts, size_t nverts, int dims, int strip, const float* M, const float color[4], float width) {
     const size_t nseg = strip ? (nverts >= 2 ? nverts - 1 : 0) : nverts / 2;
     int wpx = (int)floorf(width + 0.5f); if (!(wpx >= 1)) wpx = 1; if (wpx > 64) wpx = 64;
-    const float a = color[3], om = 1.0f - a;
-    const float sr = color[0] * a, sg = color[1] * a, sb = color[2] * a, sa = a * a;
+    float col[4]; for (int q = 0; q < 4; ++q) col[q] = fminf(fmaxf(color[q], 0.0f), 1.0f);      // clamped like every fragment colour
+    const float a = col[3], om = 1.0f - a;
+    const float sr = col[0] * a, sg = col[1] * a, sb = col[2] * a, sa = a * a;
     for (size_t s = 0; s < nseg; ++s) {
         const size_t i0 = strip ? s : 2 * s, i1 = i0 + 1;
         float c0[4], c1[4];

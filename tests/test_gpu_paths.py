@@ -277,3 +277,76 @@ def test_overlay_lines_then_splats(gs4d, oracle, monkeypatch):
     diff = np.abs(img.astype(np.float64) - eimg).max(axis=2)
     assert (diff > 1e-5).mean() < 1e-5 and diff.max() <= TOL
     ctx.close()
+
+
+@pytest.mark.parametrize("path", ["auto", "ordered"])
+def test_fragment_colours_are_clamped_like_the_rop(gs4d, oracle, monkeypatch, path):
+    """The reference blends into an RGBA8 window: the GL clamps every fragment's colour and alpha to [0, 1] first.  Colours above 1,
+    negative ones, alpha above 1 and uMinOpacity above 1 must therefore give the clamped picture, in the 4D and in the 3D-Full pipeline."""
+    n, W, H = 3000, 512, 384
+    ctx = _ctx(gs4d, W, H, monkeypatch, **({"GS4D_DRAW_PATH": "ordered"} if path == "ordered" else {}))
+    pos4, q, sc, life, fade, vel, rgba = scenes.cube_params_4d(n, seed=81)
+    rgba = rgba * np.array([2.5, 1.0, 1.7, 1.6], np.float32) - np.array([0.3, 0.0, 0.2, 0.0], np.float32)
+    rec = gs4d.build_records_4d(pos4 * np.array([0.25, 0.25, 0.25, 1.0], np.float32), q, sc * 5.0, life, fade, vel, rgba)
+    cam = ((150.0, 100.0, -60.0), (-0.77, -0.57, 0.27))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    db = ctx.buffer(rec)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_DIRECT)
+    ctx.bind(1, db)
+    for t, mo in ((10.0, 0.0), (10.0, 1.3)):
+        ctx.clear()
+        ctx.set_uniforms(time=t, min_opacity=mo, view=view, proj=proj)
+        ctx.draw_instanced(n)
+        eimg = oracle.composite(oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, mo), None, oracle.MODE_4D, W, H, oracle.clear_image(W, H))
+        img = ctx.read_pixels()
+        assert linf(img, eimg) <= TOL
+        assert img.min() >= 0.0 and img.max() <= 1.0 + 1e-6
+    # 3D-Full: colour * c is clamped per fragment
+    m = 200
+    pos, q, sc, rgba = scenes.cube_params(m, seed=82)
+    rgba = rgba * np.array([3.0, 0.5, 2.0, 1.5], np.float32)
+    verts = np.stack([gs4d.splat3d_mesh(pos[i] * 0.05, q[i], sc[i] * 2.0, rgba[i]) for i in range(m)])
+    vb = ctx.buffer(verts)
+    ctx.set_mode(gs4d.MODE_3D_FULL)
+    ctx.clear()
+    ctx.draw_quads(vb, m)
+    eimg = oracle.composite(oracle.preprocess(oracle.MODE_3D, verts, view, proj, W, H), None, oracle.MODE_3D, W, H, oracle.clear_image(W, H))
+    assert linf(ctx.read_pixels(), eimg) <= TOL
+    assert np.abs(eimg - oracle.clear_image(W, H)).max() > 0.05
+    ctx.close()
+
+
+def test_projection_matrix_contract_and_near_plane_clip(gs4d, oracle, monkeypatch):
+    """uProj must have glm::perspective's sparsity (anything else is refused, not drawn differently); and the quad's own clip-space z —
+    ps.z + uProj[3][2] at w = 1 (Splat4DVertexShaderInstanced.GLSL:147) — is clipped to [-1, 1] by the GL: with a near plane of 30 and a
+    far plane of 60 that removes every splat the shader's own NDC test lets through."""
+    n, W, H = 20000, 400, 300
+    ctx = _ctx(gs4d, W, H, monkeypatch)
+    pos, q, sc, rgba = scenes.cube_params(n, seed=83)
+    rec = gs4d.build_records_3d(pos * 0.2, q, sc * 3.0, rgba)
+    cam = ((0.0, 0.0, 80.0), (0.0, 0.0, -1.0))
+    view = gs4d.look_at(cam[0], cam[1])
+    db = ctx.buffer(rec)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_DIRECT)
+    ctx.bind(1, db)
+    for znear, zfar in ((0.1, 5000.0), (30.0, 60.0), (0.3, 500.0)):
+        proj = gs4d.perspective(scenes.FOV, W, H, znear, zfar)
+        ctx.clear()
+        ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+        ctx.draw_instanced(n)
+        eproj = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H)
+        eimg = oracle.composite(eproj, None, oracle.MODE_4D, W, H, oracle.clear_image(W, H))
+        assert linf(ctx.read_pixels(), eimg) <= TOL
+        assert np.array_equal(ctx.debug_projected(n)[:, 14] != 0, eproj["valid"] != 0)
+        if znear == 30.0:
+            assert eproj["valid"].sum() == 0                    # ps.z + P[3][2] < -1 for everything in front of the far plane
+        else:
+            assert eproj["valid"].sum() > n // 2
+    bad = gs4d.perspective(scenes.FOV, W, H, 0.1, 100.0).copy()
+    bad[12] = 0.25                                              # an off-centre projection: not what the quad set-up assumes
+    ctx.set_uniforms(proj=bad)
+    with pytest.raises(gs4d.Gs4dError):
+        ctx.draw_instanced(n)
+    ctx.close()
