@@ -139,9 +139,7 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
     case 6: GS4D_V2(6); break;
     case 8: GS4D_V2(8); break;
     case 12: GS4D_V2(12); break;
-    case 16: GS4D_V2(16); break;
-    case 24: GS4D_V2(24); break;
-    default: GS4D_V2(32); break;
+    default: GS4D_V2(16); break;
     }
 #undef GS4D_V2
     return hipGetLastError();

@@ -27,7 +27,7 @@ using namespace gs4d;
 
 namespace {
 
-constexpr int MAX_LANES = 4;
+constexpr int MAX_LANES = 8;
 
 struct Buffer {
     void* d = nullptr;
@@ -404,7 +404,7 @@ int resolve_lane(gs4d_ctx* c, int li) {
             // the compositor's occupancy falls with the list capacity it is launched for: give capacity back when the lists stay short
             const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, L.host_total[5] + L.host_total[5] / 8u));
             if (!flags && fit < c->list_hint) { if (++c->shrink_votes >= 8) { c->list_hint = fit; c->shrink_votes = 0; } } else c->shrink_votes = 0;
-            if (!flags && c->slabs > 1u && L.host_total[5] * 3u < V2_LIST_TARGET) { if (++c->unslab_votes >= 16) { c->slabs /= 2u; c->list_hint = v2_list_capacity(V2_LIST_TARGET); c->unslab_votes = 0; } } else c->unslab_votes = 0;
+            if (!flags && c->slabs > 1u && L.host_total[5] * 3u < V2_MAX_LIST) { if (++c->unslab_votes >= 16) { c->slabs /= 2u; c->list_hint = V2_MAX_LIST; c->unslab_votes = 0; } } else c->unslab_votes = 0;
         }
         if (!flags) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)");
@@ -412,17 +412,19 @@ int resolve_lane(gs4d_ctx* c, int li) {
         c->stat_entries = total;
         const bool was_v2 = L.pending_args.v2;     // an unordered draw kept no copy of its sort index: whatever path the re-run takes, it starts from the projection
         if (L.pending_args.v2 && (flags & 2u)) {
-            // A list longer than the compositor was launched for.  Short lists keep the compositor's occupancy up (its LDS and registers
-            // grow with the capacity), so lists are first cut into more depth slabs — each sub-list is ordered by itself — until the
-            // longest sub-list fits V2_LIST_TARGET; only then does the capacity grow, and past V2_MAX_LIST the draw leaves the unordered path.
-            // The estimate uses the geometry THIS attempt was launched with (another lane's attempt may have changed the context's since).
+            // A list longer than the compositor was launched for.
             const uint32_t longest = L.host_total[5], launched = L.tl.slabs;
-            uint32_t want = launched;
-            while (want < V2_MAX_SLABS && (uint64_t)longest * launched > (uint64_t)want * (V2_LIST_TARGET - V2_LIST_TARGET / 4u) && (want * 2u) <= (1u << std::min(30, L.pending_args.keybits))) want *= 2u;
-            if (want > c->slabs) c->slabs = want;
-            const uint32_t expect = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (uint64_t)longest * launched / c->slabs);      // if the keys spread evenly over the slabs
-            if (c->slabs == launched && longest > V2_MAX_LIST) { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; }      // slabs cannot help any further
-            else c->list_hint = std::max(c->slabs > launched ? 0u : c->list_hint, v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, expect + expect / 4u)));
+            if (longest <= V2_MAX_LIST) c->list_hint = std::max(c->list_hint, v2_list_capacity(longest + longest / 8u));      // a longer list capacity is enough
+            else {
+                // Longer than the compositor can hold: cut the lists into depth slabs (each sub-list is ordered by itself) if a few slabs
+                // bring the expected sub-list under the limit — slabs cost the compositor a sort per sub-list, so as few as possible —
+                // otherwise this is a scene for the instance-ordered path.  The estimate uses the geometry THIS attempt was launched with.
+                uint32_t want = launched;
+                while (want < V2_MAX_SLABS && (uint64_t)longest * launched > (uint64_t)want * (V2_MAX_LIST - V2_MAX_LIST / 4u) && (want * 2u) <= (1u << std::min(30, L.pending_args.keybits))) want *= 2u;
+                const bool helps = (uint64_t)longest * launched <= (uint64_t)want * V2_MAX_LIST && want > launched;
+                if (helps) { c->slabs = std::max(c->slabs, want); c->list_hint = V2_MAX_LIST; }
+                else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; }
+            }
         }
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;

@@ -112,13 +112,12 @@ struct TileCount {                               // hist == nullptr: the ordered
     int tiles_x = 0, shard_rank = 0, shard_world = 1;
     KeySrc ks;
 };
-constexpr uint32_t V2_MAX_LIST = 2048;           // longest list the compositor sorts in LDS.  Longer per-tile lists are cut into depth slabs (below); beyond V2_MAX_SLABS a draw uses the ordered path
-constexpr uint32_t V2_LIST_TARGET = 512;         // sub-list length the slab count aims for
-constexpr uint32_t V2_MAX_SLABS = 16;            // a tile's list is kept as `slabs` sub-lists by the top bits of the blend key: far slab first, each ordered by itself in the compositor
+constexpr uint32_t V2_MAX_LIST = 1024;           // longest list the compositor sorts in LDS (beyond ~1000 entries per tile its LDS footprint costs more occupancy than the ordered path's two sort passes cost time).  Longer per-tile lists are cut into depth slabs (below); beyond V2_MAX_SLABS a draw uses the ordered path
+constexpr uint32_t V2_MAX_SLABS = 4;            // a tile's list is kept as `slabs` sub-lists by the top bits of the blend key: far slab first, each ordered by itself in the compositor
 constexpr int SEG_THREADS = 512;                 // workgroup size of the kernels that walk a segment of records (k_preprocess<.., true>, k_bucket_scatter)
 // list capacities the compositor is instantiated for (64 entries per lane-register): the smallest one >= n
 inline uint32_t v2_list_capacity(uint32_t n) {
-    static const uint32_t ladder[] = { 64, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048 };
+    static const uint32_t ladder[] = { 64, 128, 192, 256, 384, 512, 768, 1024 };
     for (uint32_t c : ladder) if (n <= c) return c;
     return V2_MAX_LIST;
 }

@@ -100,8 +100,8 @@ hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, 
 #else
 #define OS_STAMP(k) do { } while (0)
 #endif
-constexpr uint32_t OS_GROUP = 32;         // tiles per look-back group
-constexpr uint32_t OS_SUPER = 32;         // groups per super-group
+constexpr uint32_t OS_GROUP = 16;         // tiles per look-back group (every look-back word in flight at once is a live register: 32 x 32 held the kernel at 177 VGPRs = one workgroup per CU)
+constexpr uint32_t OS_SUPER = 16;         // groups per super-group
 typedef unsigned long long u64;
 
 struct OsBufs { uint32_t* k[3]; uint32_t* v[3]; };      // [0] caller's buffers, [1],[2] scratch
