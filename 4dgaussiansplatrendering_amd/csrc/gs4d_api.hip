@@ -7,7 +7,7 @@
 //   radix_sort::sorter::sort                                Dependencies/GPU_RADIX_SORT/radix_sort.hpp:258-392
 //   Renderer::Clear / Renderer::Draw                        4DSplatRendering/Renderer.cpp:20-39
 //
-// Execution model: FRAME LANES.  A context owns a few lanes (2 by default, GS4D_LANES=1..4); a lane is one HIP stream with its own framebuffer,
+// Execution model: FRAME LANES.  A context owns a few lanes (4 by default, GS4D_LANES=1..8); a lane is one HIP stream with its own framebuffer,
 // projected records, tile lists and sort scratch.  Every call of one frame (key generation, depth sort, draw) is queued on the
 // current lane, in order — no events inside a frame.  The first frame-starting call (clear, keygen, sort) after a draw moves to the
 // next lane, so whole frames overlap on the device: the latency-bound kernels of one frame (the radix sort's chained scans) fill the
@@ -98,7 +98,7 @@ thread_local std::string g_create_error;
 struct gs4d_ctx {
     int device = 0;
     int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
-    int nlanes = 2, cur = 0;
+    int nlanes = 4, cur = 0;
     Lane lanes[MAX_LANES];
     Framebuffer fbs[MAX_LANES];        // fbs[i] belongs to lane i; a clear makes the current lane's own framebuffer the current one
     int cur_fb = 0;

@@ -56,7 +56,7 @@ def algorithmic_bytes(n, w, h):
 class Scene:
     """One context with its resident buffers and the per-frame call sequence."""
 
-    def __init__(self, gs4d, records, cam, view, proj, device, keybufs=2, lanes=None):
+    def __init__(self, gs4d, records, cam, view, proj, device, keybufs=4, lanes=None):
         old = os.environ.get("GS4D_LANES")
         if lanes is not None:
             os.environ["GS4D_LANES"] = str(lanes)
@@ -143,7 +143,7 @@ def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file):
             "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
 
 
-def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None, keybufs=2):
+def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None, keybufs=4):
     """One GPU, static 3D splats in the cube (configs[1] / configs[2]).  Returns (result dict, records)."""
     cam = scenes.CAM_CUBE
     view = gs4d.look_at(cam[0], cam[1])
@@ -220,7 +220,7 @@ def main():
 
 def single_gpu(args, gs4d, scenes, device):
     n = args.splats
-    kb = args.keybufs or args.lanes or 2
+    kb = args.keybufs or args.lanes or 4          # one pair per frame lane (the library default is 4 lanes)
     res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
     tfile = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{'c2' if n == 1_000_000 else 'c3' if n == 10_000_000 else 'x'}.json")
     roofline = roofline_block(res["stats"], res["stage_ms"], res["warm_ms"], n, res["ms_per_step"], tfile)
@@ -243,7 +243,7 @@ def single_gpu(args, gs4d, scenes, device):
         "value": res["value"], "unit": "splats/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "timing": f"median of {args.windows} windows of {args.steps} steps, each window between two synchronisations; a step is pipelined throughput (two frame lanes in flight)",
+        "timing": f"median of {args.windows} windows of {args.steps} steps, each window between two synchronisations; a step is pipelined throughput ({st_lanes} frame lanes in flight)".replace("{st_lanes}", str(res["stats"]["lanes"])),
         "windows_ms_per_step": res["windows_ms_per_step"],
         "latency_ms_one_lane": latency,
         "config": {"workload": f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else ""),
@@ -282,27 +282,29 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
     pipelined = ctx.stats()["lanes"] >= 2                                 # with one frame lane there is no previous image to read
 
     def sweep(_k):
-        """One step: this rank's frames of the 256-frame sweep; presentation is software-pipelined as a swap chain is — frame j is queued
-        first, then frame j-1 (the previous image) is packed to RGBA8 into the batch; every G frames the batch is gathered on rank 0."""
-        slot, pending = 0, False
-        for j in range(most):
+        """One step: this rank's frames of the 256-frame sweep.  Presentation is software-pipelined as a swap chain is — frame j is queued
+        first, then frame j-1 (the previous image) is packed to RGBA8 into the batch — and every G presented frames the batch is gathered
+        on rank 0.  Every rank counts `most` presentations (a rank with one frame fewer skips the read of its last slot), so all ranks
+        make the same collective calls whatever the world size."""
+        state = {"p": 0}
+
+        def present(j, frames_back):
             if j < len(mine):
-                sc.frame(sharding.sweep_time(mine[j], SWEEP_FRAMES))
-                if pipelined and pending:
-                    ctx.read_frame_rgba8_device(1, batch[slot].data_ptr(), H * W * 4)
-                    slot += 1
-                elif not pipelined:
-                    ctx.read_frame_rgba8_device(0, batch[slot].data_ptr(), H * W * 4)
-                    slot += 1
-                pending = pipelined
-            last = j == most - 1
-            if last and pending:                                          # the last frame of the sweep is presented inside the sweep
-                ctx.read_frame_rgba8_device(0, batch[slot].data_ptr(), H * W * 4)
-                slot += 1
-                pending = False
-            if slot == G or (last and slot > 0) or (last and world > 1 and (most % G) and slot == 0 and j >= len(mine)):
+                ctx.read_frame_rgba8_device(frames_back, batch[state["p"] % G].data_ptr(), H * W * 4)
+            state["p"] += 1
+            if state["p"] % G == 0 or state["p"] == most:
                 sharding.gather_frames(dist, batch if backend == "nccl" else batch.cpu(), gathered, dst=0)
-                slot = 0
+
+        for j in range(most):
+            rendered = j < len(mine)
+            if rendered:
+                sc.frame(sharding.sweep_time(mine[j], SWEEP_FRAMES))
+            if not pipelined:
+                present(j, 0)
+            elif j >= 1:
+                present(j - 1, 1 if rendered else 0)      # no new frame was started: frame j-1 is still the current image
+        if pipelined:
+            present(most - 1, 0)                          # the last frame of the sweep is presented inside the sweep
 
     def fence():
         ctx.finish()

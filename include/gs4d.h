@@ -14,7 +14,7 @@
  * receives from glm::mat4.  Buffers are named by small integers like GL buffer names; 0 is "none";
  * deleting 0 or an already-deleted name is tolerated (the reference double-deletes, Scenes.h:220-224, 291-299).
  * Calls return as soon as their work is queued; only the read-back / finish calls block.  Results are as if the calls had run one
- * after another.  Internally a context spreads consecutive FRAMES over a few HIP streams ("frame lanes", 2 by default) so that they
+ * after another.  Internally a context spreads consecutive FRAMES over a few HIP streams ("frame lanes", 4 by default) so that they
  * overlap on the device: a frame is everything from one gs4d_clear / gs4d_keygen / gs4d_sort_pairs that follows a draw up to and
  * including the next draw(s); buffers and the framebuffer carry their own cross-lane ordering.  A gs4d_clear starts rendering into the
  * next image of a small swap chain (one RGBA32F image per lane); gs4d_read_pixels* read the image the last clear/draw used.
