@@ -243,7 +243,7 @@ def single_gpu(args, gs4d, scenes, device):
         "value": res["value"], "unit": "splats/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "timing": f"median of {args.windows} windows of {args.steps} steps, each window between two synchronisations; a step is pipelined throughput ({st_lanes} frame lanes in flight)".replace("{st_lanes}", str(res["stats"]["lanes"])),
+        "timing": f"median of {args.windows} windows of {args.steps} steps, each window between two synchronisations; a step is pipelined throughput ({st['lanes']} frame lanes in flight)",
         "windows_ms_per_step": res["windows_ms_per_step"],
         "latency_ms_one_lane": latency,
         "config": {"workload": f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else ""),
