@@ -60,7 +60,7 @@ struct WaveSort {
 
 template <bool PREMULT_C, int PER>
 __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
-                                                     const uint32_t* __restrict__ total, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
+                                                     const uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
                                                      float4* __restrict__ fb, int key_passes, int rec_passes, uint32_t slabs) {
     // the sort's key plane and the blend's record staging never live at the same time: one piece of LDS serves both
     constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
@@ -70,9 +70,12 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     __shared__ uint32_t er[64 * PER];
     float4* stage = reinterpret_cast<float4*>(sh_a);
     uint32_t* ek = sh_a;
-    if (total[1]) return;                                   // aborted draw (capacity or list length): the host re-runs it
     const uint32_t tile = blockIdx.x;
     const uint32_t lane = threadIdx.x;
+    // what the list kernels found out — entries, longest list, abort flags — goes to the host from here (pinned, mapped memory behind
+    // the lane's event): they are complete now, and none of them has to wait for a hand-off of its own
+    if (tile == 0u && lane == 0u) { total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = total[4]; total_host[1] = total[1]; }
+    if (total[1]) return;                                   // aborted draw (capacity or list length): the host re-runs it
     const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE;
     const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
@@ -128,9 +131,9 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
 }
 
 template <bool PREMULT_C>
-static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int W, int H,
+static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int W, int H,
                             int fb_is_clear, float4 c, float4* fb, int kp, int rp, uint32_t slabs) {
-#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
@@ -145,15 +148,15 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
     return hipGetLastError();
 }
 
-hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, int tiles_x, int tiles_y, int W, int H,
+hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs) {
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid((unsigned)(tiles_x * tiles_y));
     const int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
-    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
-                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs);
+    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
+                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs);
 }
 
 } // namespace gs4d

@@ -306,16 +306,16 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
         StageTimer t(c, GS4D_T_BINNING);
         HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
         HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, tmp, c->tiles_x, c->shard_rank, c->shard_world));
-        HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, L.host_total_dev, tmp, entries, c->list_hint));
+        HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
     }
-    HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event
     c->stat_tile_passes = 0;
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
         int recbits = 1; while (recbits < 32 && ((size_t)1 << recbits) < nrecords) ++recbits;
-        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, c->clear, F.mem,
+        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, c->clear, F.mem,
                                       c->list_hint, a.keybits, recbits, L.tl.slabs));
     }
+    HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event (the compositor's first workgroup wrote them)
     return GS4D_OK;
 }
 

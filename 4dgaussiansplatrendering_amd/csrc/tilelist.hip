@@ -16,6 +16,7 @@
 //   k_bucket_scatter        walks the same segments again: entry -> tmp[bucket start + run slot + LDS counter]   (key, tile/nb << 24 | record)
 //   k_bucket_tiles          one workgroup per bucket: counts its entries per tile in LDS, writes the tile table (first entry, count)
 //                           and moves the entries to their tile's list; the longest list is checked against the compositor's capacity
+//                           (the verdict travels to the host through the first workgroup of the compositing kernel)
 //   k_composite_v2          (composite2.hip)
 //
 // (A first version counted entries per tile with global atomics in the projection kernel and scattered with returning atomics:
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter(const uint2* __r
 constexpr int BT_THREADS = 1024, BT_ITEMS = 8, BT_COUNTERS = 256 * (int)V2_MAX_SLABS;
 __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift,
                                                              uint32_t* __restrict__ tstart, uint32_t* __restrict__ tcnt, uint2* __restrict__ entries,
-                                                             uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t hint) {
+                                                             uint32_t* __restrict__ total, uint32_t hint) {
     __shared__ uint32_t cnt[BT_COUNTERS];
     __shared__ uint32_t ws[BT_THREADS / 64];
     if (total[1] & 1u) return;                             // capacity overflow (set by k_bucket_scan); bit 1 is raised HERE by other workgroups and must not stop this one
@@ -217,18 +218,7 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
             entries[pos] = make_uint2(e[j].x, e[j].y & 0x00FFFFFFu);
         }
     }
-    // The last workgroup to finish reports to the host (pinned, mapped memory behind the lane's event).  The longest-list maximum and the
-    // flag are device-scope atomics (they execute at the memory side): once this workgroup's have been acknowledged (s_waitcnt) it may
-    // count itself in — no cache write-back.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        if (atomicAdd(&total[6], 1u) == gridDim.x - 1u) {
-            const uint32_t flags = __hip_atomic_load(&total[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t longest = __hip_atomic_load(&total[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = longest; total_host[1] = flags;
-        }
-    }
+    // (the entry count, the longest list and the flags reach the host through the compositing kernel that follows: no hand-off here)
 }
 
 bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits) {
@@ -292,8 +282,8 @@ hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rect
     return hipGetLastError();
 }
 
-hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint32_t* total_host, const uint2* tmp, uint2* entries, uint32_t hint) {
-    k_bucket_tiles<<<dim3(t.nb), dim3(BT_THREADS), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, t.tstart, t.tcnt, entries, total, total_host, hint);
+hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint) {
+    k_bucket_tiles<<<dim3(t.nb), dim3(BT_THREADS), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, t.tstart, t.tcnt, entries, total, hint);
     return hipGetLastError();
 }
 
