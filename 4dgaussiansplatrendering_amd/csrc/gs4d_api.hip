@@ -62,6 +62,8 @@ struct DrawArgs {
     int lane = 0, fb = 0;          // where the draw ran
     bool v2 = false;               // unordered tile lists (tilelist.hip); false: instance-ordered lists (binning.hip)
     KeySrc ks; int keybits = 32;   // v2: where the blend order comes from
+    // the draw also executes the gs4d_keygen + gs4d_sort_pairs that were queued for it (first run only: a re-run finds the buffers sorted)
+    bool fuse = false; gs4d_buf fuse_keys = 0, fuse_idx = 0; uint32_t fuse_span = 0xFFFFFFFFu;
 };
 
 struct Framebuffer {
@@ -120,6 +122,13 @@ struct gs4d_ctx {
     int path_pref = 0;                 // GS4D_DRAW_PATH: 0 auto, 1 ordered path only, 2 = auto (kept for symmetry)
     bool long_lists = false;           // the last unordered draw met a list longer than V2_MAX_LIST: draws use the ordered path ...
     uint64_t ordered_draws = 0;        // ... and probe the unordered one again every so often when the lists look short on average
+    // A gs4d_keygen (and the gs4d_sort_pairs of its output) is not launched at once: if the draw that follows takes its blend order from
+    // exactly that sort, the projection kernel generates the keys as a by-product (it recomputes them anyway) and the sort is queued
+    // behind the draw.  Any other call that could observe the buffers launches the stand-alone kernels first (flush_order).
+    struct { bool keygen = false, sorted = false; int lane = 0; gs4d_buf data = 0, keys = 0, idx = 0; size_t n = 0; float t = 0; float cam[3] = { 0, 0, 0 };
+             int key_mode = 0; uint32_t bias = 0, span = 0xFFFFFFFFu; float view[16] = { 0 }; } po;
+    bool defer_order = true;           // GS4D_FUSE_KEYGEN=0 switches the deferral off (test hook)
+    uint64_t stat_fused = 0;
     int shrink_votes = 0, unslab_votes = 0;
     uint32_t slabs = 1;                // depth slabs per tile list (tilelist.hip): doubled when a list outgrows V2_MAX_LIST, given back when the lists stay short
     uint32_t list_hint = 256;          // LDS list capacity the compositor is launched with (64 << k); grows on demand, validated per draw on the device
@@ -374,6 +383,15 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             const PreOut po = { L.proj, L.rects };
             TileCount tc;
             if (v2) { tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.rows = L.tl.rows; tc.tiles_x = c->tiles_x; tc.shard_rank = c->shard_rank; tc.shard_world = c->shard_world; tc.ks = a.ks; }
+            if (v2 && a.fuse) {
+                Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
+                if (!K || !I) return fail(c, GS4D_E_INVALID, "draw: the key buffers of the queued key generation have been deleted");
+                hipError_t he = hipSuccess;
+                uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, npre, &he);
+                if (!kh) return hipfail(c, he, "sort_hist_slot");
+                tc.keys_out = (float*)K->d; tc.idx_out = (uint32_t*)I->d; tc.ghist = kh; tc.span = a.fuse_span; tc.err = L.host_total_dev + 4;
+                L.depth_sort.hist_bias = a.ks.bias;
+            }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, npre, a.u, c->W, c->H, po, tc));
@@ -384,7 +402,17 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
     if (L.pair_cap < want) { int rc = ensure_pairs(c, L, want); if (rc) return rc; }
-    if (v2) return enqueue_raster_v2(c, L, F, a, npre, premult);
+    if (v2) {
+        int rc = enqueue_raster_v2(c, L, F, a, npre, premult);
+        if (rc == GS4D_OK && a.fuse) {
+            // the depth sort the application asked for: its keys and digit histograms came out of the projection kernel; nothing in this draw
+            // waits for it (the draw took its order from the keys), it fills the caller's buffers for whoever reads them next
+            Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
+            StageTimer t(c, GS4D_T_SORT);
+            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true));
+        }
+        return rc;
+    }
     return enqueue_raster(c, L, F, order, order_copy, a.instances, npre, premult, a.fb_was_clear);
 }
 
@@ -439,8 +467,11 @@ int resolve_lane(gs4d_ctx* c, int li) {
     return GS4D_OK;
 }
 
+int flush_order(gs4d_ctx* c);
+
 // every lane (calls that observe or tear down everything)
 int resolve_pending(gs4d_ctx* c) {
+    { int rc = flush_order(c); if (rc) return rc; }
     for (int i = 0; i < c->nlanes; ++i) { int rc = resolve_lane(c, i); if (rc) return rc; }
     return GS4D_OK;
 }
@@ -457,6 +488,30 @@ int host_access(gs4d_ctx* c, Buffer& B) {
     int rc = resolve_pending(c); if (rc) return rc;
     rc = sync_all(c); if (rc) return rc;
     B.wr_lane = -1; B.rd_mask = 0; B.tail_mask = 0; B.ordered_mask = 0;
+    return GS4D_OK;
+}
+
+// Launch a queued gs4d_keygen (+ gs4d_sort_pairs) as kernels of their own: somebody is about to look at the buffers, or the draw that
+// follows cannot use them.  The lane has not changed since they were queued (only frame-starting calls change it, and they flush first).
+int flush_order(gs4d_ctx* c) {
+    if (!c->po.keygen) return GS4D_OK;
+    auto po = c->po;
+    c->po.keygen = c->po.sorted = false;
+    Lane& L = c->lanes[po.lane];
+    Buffer* D = getbuf(c, po.data); Buffer* K = getbuf(c, po.keys); Buffer* I = getbuf(c, po.idx);
+    if (!D || !K || !I || !D->soa) return fail(c, GS4D_E_INVALID, "queued keygen: a buffer it names has been deleted");
+    {
+        hipError_t he = hipSuccess;
+        uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, po.n, &he);
+        if (!kh) return hipfail(c, he, "sort_hist_slot");
+        StageTimer tm(c, GS4D_T_KEYGEN);
+        HIPCHK(c, launch_keygen(L.s, D->soa, D->soa + 5 * D->soa_n, po.n, po.t, po.cam, po.view, po.key_mode, (float*)K->d, (uint32_t*)I->d, kh, po.bias, po.span, L.host_total_dev + 4));
+        L.depth_sort.hist_bias = po.bias;
+    }
+    if (po.sorted) {
+        StageTimer t(c, GS4D_T_SORT);
+        HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, po.n, nullptr, L.depth_sort.hist_bits, true));
+    }
     return GS4D_OK;
 }
 
@@ -497,6 +552,7 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     memset(&c->u, 0, sizeof c->u);
     for (int i = 0; i < 4; ++i) c->u.view[5 * i] = c->u.proj[5 * i] = 1.0f;
     if (const char* ev = getenv("GS4D_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) c->nlanes = v; }     // tuning knob
+    if (const char* ev = getenv("GS4D_FUSE_KEYGEN")) c->defer_order = atoi(ev) != 0;                                       // test hook: 0 = launch key generation and sort at once
     if (const char* ev = getenv("GS4D_DRAW_PATH")) { if (!strcmp(ev, "ordered")) c->path_pref = 1; }                         // test hook: instance-ordered tile lists for every draw
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
     for (int i = 0; i < c->nlanes; ++i) {
@@ -582,6 +638,7 @@ int gs4d_buffer_create(gs4d_ctx* c, const void* data, size_t bytes, gs4d_buf* ou
 int gs4d_buffer_subdata(gs4d_ctx* c, gs4d_buf b, size_t offset, const void* data, size_t bytes) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     Buffer* B = getbuf(c, b);
     if (!B) return fail(c, GS4D_E_INVALID, "buffer_subdata: bad buffer name");
     if (offset > B->bytes || bytes > B->bytes - offset) return fail(c, GS4D_E_INVALID, "buffer_subdata: range outside the buffer");   // GL_INVALID_VALUE
@@ -597,6 +654,7 @@ int gs4d_buffer_subdata(gs4d_ctx* c, gs4d_buf b, size_t offset, const void* data
 int gs4d_buffer_read(gs4d_ctx* c, gs4d_buf b, size_t offset, void* out, size_t bytes) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     Buffer* B = getbuf(c, b);
     if (!B) return fail(c, GS4D_E_INVALID, "buffer_read: bad buffer name");
     if (offset > B->bytes || bytes > B->bytes - offset || (!out && bytes)) return fail(c, GS4D_E_INVALID, "buffer_read: range outside the buffer");
@@ -612,6 +670,7 @@ int gs4d_buffer_read(gs4d_ctx* c, gs4d_buf b, size_t offset, void* out, size_t b
 int gs4d_buffer_destroy(gs4d_ctx* c, gs4d_buf b) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     Buffer* B = getbuf(c, b);
     if (!B) return GS4D_OK;                         // 0, unknown or already deleted: silently ignored, like glDeleteBuffers
     { int rc = resolve_pending(c); if (rc) return rc; rc = sync_all(c); if (rc) return rc; }
@@ -626,6 +685,8 @@ int gs4d_buffer_destroy(gs4d_ctx* c, gs4d_buf b) {
 
 int gs4d_buffer_device_ptr(gs4d_ctx* c, gs4d_buf b, void** dptr, size_t* bytes) {
     if (!c) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     Buffer* B = getbuf(c, b);
     if (!B) return fail(c, GS4D_E_INVALID, "buffer_device_ptr: bad buffer name");
     if (dptr) *dptr = B->d;
@@ -637,6 +698,7 @@ int gs4d_buffer_device_ptr(gs4d_ctx* c, gs4d_buf b, void** dptr, size_t* bytes) 
 int gs4d_buffer_invalidate(gs4d_ctx* c, gs4d_buf b) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     Buffer* B = getbuf(c, b);
     if (!B) return fail(c, GS4D_E_INVALID, "buffer_invalidate: bad buffer name");
     int rc = resolve_pending(c); if (rc) return rc;           // a draw that has to be re-run reads the old contents: settle those first
@@ -714,7 +776,17 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     if (!K || !V) return fail(c, GS4D_E_INVALID, "sort_pairs: bad buffer name");
     if (K == V) return fail(c, GS4D_E_INVALID, "sort_pairs: keys and values must be different buffers");
     if (n >= 0xFFFFFFFFull || K->bytes < n * 4 || V->bytes < n * 4) return fail(c, GS4D_E_INVALID, "sort_pairs: buffers smaller than n elements");
-    { int rc = next_frame_if_drawn(c); if (rc) return rc; rc = after_user_stream(c); if (rc) return rc; }
+    if (c->po.keygen && !c->po.sorted && keys == c->po.keys && vals == c->po.idx && n == c->po.n && c->cur == c->po.lane && !lane(c).drawn) {
+        // the sort of a queued key generation's own output: queued with it; what the index will have been sorted by is known now
+        Lane& Lq = lane(c);
+        { int rc = after_user_stream(c); if (rc) return rc; rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *V, true); if (rc) return rc; }
+        c->po.sorted = true;
+        c->stat_depth_passes = (uint64_t)std::max(2, (Lq.depth_sort.hist_bits + 7) / 8);
+        K->version++; V->version++;
+        V->prov_valid = true; V->prov_data = Lq.kg_data; V->prov_data_ver = Lq.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = Lq.kg_bits; V->prov_ks = Lq.kg_ks;
+        return GS4D_OK;
+    }
+    { int rc = flush_order(c); if (rc) return rc; rc = next_frame_if_drawn(c); if (rc) return rc; rc = after_user_stream(c); if (rc) return rc; }
     { int rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *V, true); if (rc) return rc; }
     Lane& L = lane(c);
     // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
@@ -739,13 +811,10 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     if (key_mode != GS4D_KEY_REF_INV_EUCLID && key_mode != GS4D_KEY_VIEW_Z) return fail(c, GS4D_E_INVALID, "keygen: unknown key mode");
     if (n >= 0xFFFFFFFFull || D->bytes < n * 96 || K->bytes < n * 4 || I->bytes < n * 4) return fail(c, GS4D_E_INVALID, "keygen: buffers smaller than n elements");
     if (n == 0) return GS4D_OK;
-    { int rc = next_frame_if_drawn(c); if (rc) return rc; rc = after_user_stream(c); if (rc) return rc; }
+    { int rc = flush_order(c); if (rc) return rc; rc = next_frame_if_drawn(c); if (rc) return rc; rc = after_user_stream(c); if (rc) return rc; }
     int rc = ensure_soa(c, *D); if (rc) return rc;
     { rc = lane_access(c, *D, false); if (rc) return rc; D->tail_mask |= 1u << c->cur; rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *I, true); if (rc) return rc; }
     Lane& L = lane(c);
-    hipError_t he = hipSuccess;
-    uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, n, &he);
-    if (!kh) return hipfail(c, he, "sort_hist_slot");
     // A proven lower bound of every key (1 / farthest possible distance, from the bounding box of the records) is subtracted inside
     // the sort's digit extraction: when the keys span less than 2^24 bit patterns above it (camera outside the cloud, far/near < 4)
     // the top digit becomes constant.  When the camera is provably outside the box the same reasoning gives an upper bound, hence
@@ -777,9 +846,11 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
             }
         }
     }
-    StageTimer tm(c, GS4D_T_KEYGEN);
-    HIPCHK(c, launch_keygen(L.s, D->soa, D->soa + 5 * D->soa_n, n, t, cam, c->u.view, key_mode, (float*)K->d, (uint32_t*)I->d, kh, bias, span, L.host_total_dev + 4));
-    L.depth_sort.hist_bias = bias;
+    // Not launched yet (see gs4d_ctx::po): everything the launch needs is recorded, everything a later call may ask about the buffers
+    // (versions, what the index will have been sorted by) is settled now.
+    c->po.keygen = true; c->po.sorted = false; c->po.lane = c->cur; c->po.data = data; c->po.keys = keys; c->po.idx = idx; c->po.n = n; c->po.t = t;
+    c->po.cam[0] = cam[0]; c->po.cam[1] = cam[1]; c->po.cam[2] = cam[2]; c->po.key_mode = key_mode; c->po.bias = bias; c->po.span = span;
+    memcpy(c->po.view, c->u.view, sizeof c->po.view);
     L.depth_sort.hist_bits = span < (1u << 8) ? 8 : span < (1u << 16) ? 16 : span < (1u << 24) ? 24 : 32;
     K->version++; I->version++;
     L.kg_buf = keys; L.kg_ver = K->version; L.kg_n = n;
@@ -788,6 +859,7 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     L.kg_ks.t = t; L.kg_ks.camx = cam[0]; L.kg_ks.camy = cam[1]; L.kg_ks.camz = cam[2];
     L.kg_ks.vr0 = c->u.view[2]; L.kg_ks.vr1 = c->u.view[6]; L.kg_ks.vr2 = c->u.view[10]; L.kg_ks.vr3 = c->u.view[14];
     L.kg_ks.bias = bias;
+    if (!c->defer_order) return flush_order(c);
     return GS4D_OK;
 }
 
@@ -837,9 +909,19 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
         }
         a.v2 = ok;
     }
+    a.fuse = false;
+    if (c->po.keygen) {
+        // a queued key generation + sort: executed by this draw if it is the draw they were made for (it takes its blend order from exactly
+        // that sort, on the same lane, and the unordered path can run), else launched on their own first
+        const bool mine = a.v2 && a.mode == GS4D_MODE_4D_SORTED && !a.quads && c->po.sorted && c->po.idx == a.order && c->po.data == a.data && c->po.lane == c->cur
+                       && tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, c->slabs, a.keybits);
+        if (mine) { a.fuse = true; a.fuse_keys = c->po.keys; a.fuse_idx = c->po.idx; a.fuse_span = c->po.span; c->po.keygen = c->po.sorted = false; c->stat_fused++; }
+        else { int rc2 = flush_order(c); if (rc2) return rc2; }
+    }
     const size_t before = L.proj_n;
     L.proj_n = 0;
     rc = run_draw(c, a, true);
+    a.fuse = false;                    // a re-run of this draw finds the keys written and the sort queued
     if (rc) { L.proj_n = before; return rc; }
     if (L.proj_n) { L.pending = true; L.pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; if (a.v2) c->stat_v2_draws++; }   // proj_n != 0 <=> raster work was enqueued
     else L.proj_n = before;
@@ -867,6 +949,7 @@ int gs4d_draw_quads(gs4d_ctx* c, gs4d_buf vertices, size_t nquads) {
 int gs4d_draw_lines(gs4d_ctx* c, const float* verts, size_t nverts, int dims, int strip, const float viewproj[16], const float rgba[4], float width) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     if (dims != 2 && dims != 3) return fail(c, GS4D_E_INVALID, "draw_lines: dims must be 2 (NDC positions) or 3 (positions transformed by viewproj)");
     if (!rgba || (dims == 3 && !viewproj) || (nverts && !verts)) return fail(c, GS4D_E_INVALID, "draw_lines: NULL argument");
     if (nverts < 2) return GS4D_OK;
@@ -913,6 +996,7 @@ int gs4d_finish(gs4d_ctx* c) {
 int gs4d_read_pixels(gs4d_ctx* c, float* rgba, size_t bytes) {
     if (!c || !rgba) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels: bytes != width*height*16");
     int rc = resolve_image(c, c->cur_fb); if (rc) return rc;
     rc = materialise_fb(c); if (rc) return rc;
@@ -954,6 +1038,7 @@ static int read_device_common(gs4d_ctx* c, int frames_back, void* dptr, bool rgb
 int gs4d_read_pixels_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (!c || !dptr) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     if (bytes != (size_t)c->W * c->H * 16) return fail(c, GS4D_E_INVALID, "read_pixels_device: bytes != width*height*16");
     return read_device_common(c, 0, dptr, false);
 }
@@ -961,6 +1046,7 @@ int gs4d_read_pixels_device(gs4d_ctx* c, void* dptr, size_t bytes) {
 int gs4d_read_pixels_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (!c || !dptr) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_pixels_rgba8_device: bytes != width*height*4");
     return read_device_common(c, 0, dptr, true);
 }
@@ -968,6 +1054,7 @@ int gs4d_read_pixels_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
 int gs4d_read_frame_rgba8_device(gs4d_ctx* c, int frames_back, void* dptr, size_t bytes) {
     if (!c || !dptr) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_frame_rgba8_device: bytes != width*height*4");
     return read_device_common(c, frames_back, dptr, true);
 }
@@ -994,6 +1081,7 @@ int gs4d_band_rows(gs4d_ctx* c, int* rows) {
 int gs4d_read_band_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (!c || !dptr) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     const int rows = band_pixel_rows(c);
     if (bytes != (size_t)rows * c->W * 4) return fail(c, GS4D_E_INVALID, "read_band_rgba8_device: bytes != band_rows*width*4");
     int rc = resolve_image(c, c->cur_fb); if (rc) return rc;
@@ -1023,6 +1111,7 @@ int gs4d_set_stream(gs4d_ctx* c, void* hip_stream) {
 int gs4d_set_profiling(gs4d_ctx* c, int stage_mask) {
     if (!c) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     if (stage_mask && c->ev0.empty()) {
         const size_t n = (size_t)gs4d_ctx::PROF_FRAMES * GS4D_T_COUNT;
         c->ev0.assign(n, nullptr); c->ev1.assign(n, nullptr); c->ran.assign(n, 0);
@@ -1086,13 +1175,14 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
     stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = c->stat_reruns; stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
-    stats[4] = c->stat_depth_passes; stats[5] = c->stat_tile_passes; stats[6] = (uint64_t)c->nlanes; stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
+    stats[4] = c->stat_depth_passes; stats[5] = c->stat_tile_passes; stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }
 
 int gs4d_debug_read_projected(gs4d_ctx* c, float* out16, size_t nrecords) {
     if (!c || !out16) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
     Lane& L = lane(c);
     if (nrecords > L.proj_n) return fail(c, GS4D_E_INVALID, "debug_read_projected: more records than the last draw projected");
     int rc = resolve_pending(c); if (rc) return rc;

@@ -111,6 +111,9 @@ struct TileCount {                               // hist == nullptr: the ordered
     uint32_t nb = 0, seg = 0;                    // buckets (a power of two), records per segment (a multiple of SEG_THREADS; one workgroup walks one segment)
     int tiles_x = 0, shard_rank = 0, shard_world = 1;
     KeySrc ks;
+    // Fused key generation (the draw executes a gs4d_keygen + gs4d_sort_pairs that were queued just before it): the projection kernel also
+    // writes the caller's key and index buffers and accumulates the digit histograms of the depth sort, exactly as k_keygen would
+    float* keys_out = nullptr; uint32_t* idx_out = nullptr; uint32_t* ghist = nullptr; uint32_t span = 0xFFFFFFFFu; uint32_t* err = nullptr;
 };
 constexpr uint32_t V2_MAX_LIST = 1024;           // longest list the compositor sorts in LDS (beyond ~1000 entries per tile its LDS footprint costs more occupancy than the ordered path's two sort passes cost time).  Longer per-tile lists are cut into depth slabs (below); beyond V2_MAX_SLABS a draw uses the ordered path
 constexpr uint32_t V2_MAX_SLABS = 4;            // a tile's list is kept as `slabs` sub-lists by the top bits of the blend key: far slab first, each ordered by itself in the compositor

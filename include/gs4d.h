@@ -153,7 +153,7 @@ GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);           
 GS4D_API int gs4d_get_timeline(gs4d_ctx* ctx, float* ms, int max_frames, int* frames);
 GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[8]);                    /* [0] tile-list entries of the last draw, [1] capacity, [2] re-runs after overflow, [3] tiles,
                                                                                       [4] radix passes launched by the last gs4d_sort_pairs, [5] by the last draw's tile sort (0: the draw built unordered tile lists),
-                                                                                      [6] frame lanes, [7] low 32 bits: draws so far on the unordered tile-list path, high 32 bits: longest tile list of the last such draw */
+                                                                                      [6] low 32 bits: frame lanes, high 32 bits: draws that generated the depth keys of the preceding gs4d_keygen themselves (see gs4d_keygen), [7] low 32 bits: draws so far on the unordered tile-list path, high 32 bits: longest tile list of the last such draw */
 /* Projected records of the last draw, 16 floats per record in record order:
  * cx, cy, a0x, a0y, a1x, a1y, alpha, r, g, b, tile-rect (2 words, bit patterns), hx, hy, valid(1/0), 0 */
 GS4D_API int gs4d_debug_read_projected(gs4d_ctx* ctx, float* out16, size_t nrecords);

@@ -353,3 +353,109 @@ def test_projection_matrix_contract_and_near_plane_clip(gs4d, oracle, monkeypatc
     with pytest.raises(gs4d.Gs4dError):
         ctx.draw_instanced(n)
     ctx.close()
+
+
+# ---- key generation executed by the draw that consumes it (gs4d_keygen / gs4d_sort_pairs queued, k_project_count<., true>) ----
+def _frames_with_late_reads(ctx, gs4d, rec, cams, W, H, key_mode=None):
+    """The reference's frame (Scenes.h:305-345): keygen, sort, draw - nothing looks at the key buffers in between; read them afterwards."""
+    n = rec.shape[0]
+    db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    out = []
+    for k, cam in enumerate(cams):
+        view, proj = cam_mats(gs4d, cam, W, H)
+        t = 0.25 * k
+        ctx.clear()
+        ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+        ctx.keygen(db, t, cam[0], kb, ib, n, **({} if key_mode is None else {"key_mode": key_mode}))
+        ctx.sort_pairs(kb, ib, n)
+        ctx.set_mode(gs4d.MODE_4D_SORTED)
+        ctx.bind(1, ib)
+        ctx.bind(2, db)
+        ctx.draw_instanced(n)
+        out.append((ctx.read_pixels(), ctx.read(kb, np.uint32, n), ctx.read(ib, np.uint32, n)))
+    st = ctx.stats()
+    for b in (db, kb, ib):
+        ctx.delete(b)
+    return out, st
+
+
+def _expected_frame(oracle, rec, t, cam, view, proj, W, H, viewz):
+    eidx, ekeys = oracle.keygen_viewz(rec, t, view) if viewz else oracle.keygen(rec, t, cam[0])
+    skeys, eperm = oracle.sort_pairs(ekeys.view(np.uint32), eidx, "std")
+    eproj = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, 0.0)
+    return ekeys.view(np.uint32), skeys, eperm, eproj
+
+
+@pytest.mark.parametrize("key_mode", ["euclid", "view_z"])
+def test_draw_that_generates_its_own_depth_keys(gs4d, oracle, monkeypatch, key_mode):
+    n, W, H = 120000, 1280, 720
+    pos4, q, sc, life, fade, vel, rgba = scenes.cube_params_4d(n, seed=47)
+    rec = gs4d.build_records_4d(pos4, q, sc * 2.0, life, fade, vel, rgba)
+    c0 = scenes.CAM_CUBE
+    far = (tuple(1.15 * np.asarray(c0[0], np.float32)),) + tuple(c0[1:])
+    near = (tuple(0.85 * np.asarray(c0[0], np.float32)),) + tuple(c0[1:])
+    cams = [c0, far, near, c0, far, near]                            # more frames than lanes: every lane is used again
+    km = None if key_mode == "euclid" else gs4d.KEY_VIEW_Z
+    res = {}
+    for fuse in (1, 0):
+        ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_FUSE_KEYGEN=fuse)
+        res[fuse], st = _frames_with_late_reads(ctx, gs4d, rec, cams, W, H, km)
+        ctx.close()
+        assert st["fused_keygen_draws"] == (len(cams) if fuse else 0)
+        assert st["unordered_draws"] == len(cams)
+    for k, cam in enumerate(cams):
+        view, proj = cam_mats(gs4d, cam, W, H)
+        _, skeys, eperm, eproj = _expected_frame(oracle, rec, 0.25 * k, cam, view, proj, W, H, km is not None)
+        eimg = oracle.composite(eproj, eperm, oracle.MODE_4D, W, H, oracle.clear_image(W, H))
+        for fuse in (1, 0):
+            img, keys_sorted, perm = res[fuse][k]
+            assert np.array_equal(perm, eperm), (fuse, k)
+            assert np.array_equal(keys_sorted, skeys), (fuse, k)
+            assert linf(img, eimg) <= TOL, (fuse, k)
+        assert np.array_equal(res[1][k][0], res[0][k][0])            # the same frame bit for bit either way
+
+
+def test_queued_keygen_is_launched_when_something_else_follows(gs4d, oracle, monkeypatch):
+    """The queue is only an optimisation: reads, a draw from another index, a second keygen, an upload all see finished buffers."""
+    n, W, H = 20000, 640, 360
+    pos4, q, sc, life, fade, vel, rgba = scenes.cube_params_4d(n, seed=48)
+    rec = gs4d.build_records_4d(pos4, q, sc * 2.0, life, fade, vel, rgba)
+    cam, t = scenes.CAM_CUBE, 3.0
+    view, proj = cam_mats(gs4d, cam, W, H)
+    ekeys, skeys, eperm, eproj = _expected_frame(oracle, rec, t, cam, view, proj, W, H, False)
+    eimg = oracle.composite(eproj, eperm, oracle.MODE_4D, W, H, oracle.clear_image(W, H))
+    ctx = _ctx(gs4d, W, H, monkeypatch)
+    db, kb, ib, kb2, ib2 = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+    # (a) keygen alone, then read: unsorted keys, identity index
+    ctx.keygen(db, t, cam[0], kb, ib, n)
+    assert np.array_equal(ctx.read(kb, np.uint32, n), ekeys)
+    assert np.array_equal(ctx.read(ib, np.uint32, n), np.arange(n, dtype=np.uint32))
+    # (b) keygen + sort, then a keygen into other buffers: the first pair is finished first
+    ctx.keygen(db, t, cam[0], kb, ib, n)
+    ctx.sort_pairs(kb, ib, n)
+    ctx.keygen(db, t, cam[0], kb2, ib2, n)
+    ctx.sort_pairs(kb2, ib2, n)
+    # (c) ... and the draw takes its order from the FIRST index: the queued second pair is launched on its own, not by the draw
+    ctx.clear()
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.bind(1, ib)
+    ctx.bind(2, db)
+    ctx.draw_instanced(n)
+    assert linf(ctx.read_pixels(), eimg) <= TOL
+    assert np.array_equal(ctx.read(ib, np.uint32, n), eperm)
+    assert np.array_equal(ctx.read(ib2, np.uint32, n), eperm)
+    assert np.array_equal(ctx.read(kb2, np.uint32, n), skeys)
+    assert ctx.stats()["fused_keygen_draws"] == 0
+    # (d) keygen + sort, the index uploaded over, draw: the draw blends in the uploaded order (here the reverse: front to back)
+    ctx.keygen(db, t, cam[0], kb, ib, n)
+    ctx.sort_pairs(kb, ib, n)
+    rev = np.ascontiguousarray(eperm[::-1])
+    ctx.subdata(ib, rev)
+    ctx.clear()
+    ctx.draw_instanced(n)
+    assert linf(ctx.read_pixels(), oracle.composite(eproj, rev, oracle.MODE_4D, W, H, oracle.clear_image(W, H))) <= TOL
+    assert ctx.stats()["fused_keygen_draws"] == 0
+    ctx.close()
