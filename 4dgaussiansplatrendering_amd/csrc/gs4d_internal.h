@@ -34,7 +34,6 @@ struct SortScratch {
     int hist_bits = 32;                // host-proven width of (key - hist_bias): passes above it are not even launched
     uint32_t hist_bias = 0;            // ... of (key - hist_bias): a lower bound of all keys, which makes the high digits constant (and their passes skipped)
     uint32_t epoch = 0;                // tag of the look-back words of the latest pass launch
-    uint32_t ticket_base = 0;          // value of the ticket counter (totals[64]) at the start of the next pass launch
     bool atomic_rank = false;          // LDS-atomic ranking verified on this device (lds_atomic_order_selftest)
     int shape_knob = 0, rank_knob = 0; // test / tuning hooks read at context creation: GS4D_SORT_SHAPE (1..6: tile shape of a pass), GS4D_SORT_RANK (1 = ballot ranking, 2 = LDS-atomic ranking)
     uint32_t* totals = nullptr;                                             // [256] spare words (err word when `err` is not set)

@@ -199,41 +199,41 @@ __device__ __forceinline__ uint32_t os_tiles_finish(const uint32_t* st, int32_t 
 
 // accumulator rows t+k0 .. t+rows-1 are outstanding and row t+k0 is known to be incomplete (complete = `expect` arrivals)
 template <int LB>
-__device__ __forceinline__ uint32_t os_acc_finish(const u64* acc, uint32_t t, int rows, int k0, uint32_t sum, uint32_t expect, uint32_t tid, uint32_t* err) {
+__device__ __forceinline__ uint32_t os_acc_finish(const uint32_t* acc, uint32_t t, int rows, int k0, uint32_t sum, uint32_t expect, uint32_t tid, uint32_t* err) {
     uint32_t spins = 0;
     while (true) {
         while (true) {
             __builtin_amdgcn_s_sleep(8);
-            const u64 w = __hip_atomic_load(acc + (size_t)(t + k0) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(w >> 32) == expect) { sum += (uint32_t)w; break; }
+            const uint32_t w = __hip_atomic_load(acc + (size_t)(t + k0) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((w >> 24) == expect) { sum += w & 0xFFFFFFu; break; }
             if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return sum; }
         }
         if (++k0 >= rows) return sum;
-        u64 sv[LB];
+        uint32_t sv[LB];
 #pragma unroll
-        for (int k = 0; k < LB; ++k) sv[k] = (k >= k0 && k < rows) ? __hip_atomic_load(acc + (size_t)(t + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        for (int k = 0; k < LB; ++k) sv[k] = (k >= k0 && k < rows) ? __hip_atomic_load(acc + (size_t)(t + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         bool missing = false;
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
             if (missing || k < k0 || k >= rows) continue;
-            if ((uint32_t)(sv[k] >> 32) != expect) { k0 = k; missing = true; continue; }
-            sum += (uint32_t)sv[k];
+            if ((sv[k] >> 24) != expect) { k0 = k; missing = true; continue; }
+            sum += sv[k] & 0xFFFFFFu;
         }
         if (!missing) return sum;
     }
 }
 
 // Exclusive prefix of tile `tile` for digit `tid`: earlier tiles of its group + earlier groups of its super-group + earlier super-groups.
-__device__ __forceinline__ uint32_t os_lookback(const uint32_t* st, const u64* acc, uint32_t acc_groups, uint32_t tile, uint32_t tid, uint32_t epoch, uint32_t* err) {
+__device__ __forceinline__ uint32_t os_lookback(const uint32_t* st, const uint32_t* acc, uint32_t acc_groups, uint32_t tile, uint32_t tid, uint32_t epoch, uint32_t* err) {
     const uint32_t grp = tile / OS_GROUP, sup = grp / OS_SUPER;
     const int rows_t = (int)(tile - grp * OS_GROUP), rows_g = (int)(grp - sup * OS_SUPER);
     const int32_t hi = (int32_t)tile - 1;
     const uint32_t g0 = sup * OS_SUPER;
-    uint32_t tv[OS_GROUP]; u64 gv[OS_SUPER];
+    uint32_t tv[OS_GROUP], gv[OS_SUPER];
 #pragma unroll
     for (int k = 0; k < (int)OS_GROUP; ++k) tv[k] = k < rows_t ? __hip_atomic_load(st + (size_t)(hi - k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
-    for (int k = 0; k < (int)OS_SUPER; ++k) gv[k] = k < rows_g ? __hip_atomic_load(acc + (size_t)(g0 + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    for (int k = 0; k < (int)OS_SUPER; ++k) gv[k] = k < rows_g ? __hip_atomic_load(acc + (size_t)(g0 + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     uint32_t sum_t = 0, sum_g = 0, sum_s = 0;
     int miss_t = -1, miss_g = -1;
 #pragma unroll
@@ -245,24 +245,24 @@ __device__ __forceinline__ uint32_t os_lookback(const uint32_t* st, const u64* a
 #pragma unroll
     for (int k = 0; k < (int)OS_SUPER; ++k) {
         if (miss_g >= 0 || k >= rows_g) continue;
-        if ((uint32_t)(gv[k] >> 32) != OS_GROUP) { miss_g = k; continue; }
-        sum_g += (uint32_t)gv[k];
+        if ((gv[k] >> 24) != OS_GROUP) { miss_g = k; continue; }
+        sum_g += gv[k] & 0xFFFFFFu;
     }
     // earlier super-groups (sorts of more than 1024 tiles only), 16 at a time
-    const u64* sacc = acc + (size_t)acc_groups * 256u;
+    const uint32_t* sacc = acc + (size_t)acc_groups * 256u;
     for (uint32_t t = 0; t < sup; t += 16u) {
         const int rows = (int)min(16u, sup - t);
-        u64 sv[16];
+        uint32_t sv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sv[k] = k < rows ? __hip_atomic_load(sacc + (size_t)(t + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        for (int k = 0; k < 16; ++k) sv[k] = k < rows ? __hip_atomic_load(sacc + (size_t)(t + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         int miss = -1;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if (miss >= 0 || k >= rows) continue;
-            if ((uint32_t)(sv[k] >> 32) != OS_GROUP * OS_SUPER) { miss = k; continue; }
-            sum_s += (uint32_t)sv[k];
+            if ((sv[k] >> 24) != OS_SUPER) { miss = k; continue; }
+            sum_s += sv[k] & 0xFFFFFFu;
         }
-        if (miss >= 0) sum_s = os_acc_finish<16>(sacc, t, rows, miss, sum_s, OS_GROUP * OS_SUPER, tid, err);
+        if (miss >= 0) sum_s = os_acc_finish<16>(sacc, t, rows, miss, sum_s, OS_SUPER, tid, err);
     }
     if (miss_t >= 0) sum_t = os_tiles_finish<(int)OS_GROUP>(st, hi, rows_t, miss_t, sum_t, tid, epoch, err);
     if (miss_g >= 0) sum_g = os_acc_finish<(int)OS_SUPER>(acc, g0, rows_g, miss_g, sum_g, OS_GROUP, tid, err);
@@ -283,15 +283,19 @@ __device__ __forceinline__ uint32_t digit_excl_scan(uint32_t v, uint32_t* tmp /*
     return base + inc - v;
 }
 
+// Persistent workgroups: the grid is what fits the device at once (or one workgroup per tile if that is fewer); a workgroup draws a
+// ticket, sorts that tile, draws the next.  What does not depend on the tile (histograms -> live passes and digit bases, the
+// housekeeping for the next launch) happens once per workgroup, and a finished tile's successor starts without a dispatch.
 template <int THREADS, int ITEMS, bool ATOMIC_RANK>
 __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
                                                      const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
-                                                     uint32_t* status /* [tiles][256] */, u64* acc /* [acc_groups + supers][256], zero at launch */, u64* acc_next /* zeroed here */, uint32_t acc_groups, uint32_t acc_words,
+                                                     uint32_t* status /* [tiles][256] */, uint32_t* acc /* [acc_groups + supers][256], zero at launch */, uint32_t* acc_next /* zeroed here */, uint32_t acc_groups, uint32_t acc_words,
                                                      uint32_t epoch, uint32_t* err,
-                                                     uint32_t* ticket, uint32_t ticket_base, uint32_t bias, u64* stamps /* tuning aid, may be null */) {
+                                                     uint32_t* ticket /* zero at launch */, uint32_t* ticket_next /* zeroed here */, uint32_t bias, u64* stamps /* tuning aid, may be null */) {
     constexpr uint32_t TILE_KEYS = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
     static_assert(TILE_KEYS < (1u << 14), "tile-level look-back words carry 14-bit counts");
+    static_assert((uint64_t)TILE_KEYS * OS_GROUP * OS_SUPER < (1u << 24) && OS_GROUP < 256u && OS_SUPER < 256u, "accumulators are {arrivals:8, sum:24}");
     __shared__ uint32_t skeys[TILE_KEYS];
     __shared__ uint32_t svals[TILE_KEYS];
     __shared__ uint32_t wcnt[WAVES][256];
@@ -303,12 +307,13 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
 
     const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    // Tile ids are handed out by ticket, in the order workgroups START: a tile only ever waits for tiles that are already running.
+    // Tile ids are handed out by ticket, in the order they are STARTED: a tile only ever waits for tiles that are already running.
     // (With blockIdx as the tile id, two chained-scan kernels running side by side on different streams can dead-lock each other:
     // workgroups are dispatched per XCD, so each kernel's late tiles can fill the XCD the other kernel's early tiles need.)
     // The ticket's round trip overlaps the histogram loads below, which do not depend on the tile.
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u) - ticket_base;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     if (tid == 1u) s_dead = 0u;
+    if (tid == 2u && blockIdx.x == 0) __hip_atomic_store(ticket_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch on this stream counts from zero again
     for (uint32_t q = tid; q < WAVES * 256u; q += THREADS) (&wcnt[0][0])[q] = 0u;
     uint32_t tot = 0, dead = 0;
     if (tid < 256u) {
@@ -322,118 +327,138 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     }
     __syncthreads();
     if (dead) atomicOr(&s_dead, dead);                            // at most one thread per dead pass
-    const uint32_t tile = s_tile;
     const uint32_t ntiles = (n + TILE_KEYS - 1u) / TILE_KEYS;
     // housekeeping for the NEXT launch of this sorter: its group accumulators (every workgroup a slice), its histogram slot
-    for (uint32_t q = tile * THREADS + tid; q < acc_words; q += gridDim.x * THREADS) acc_next[q] = 0ull;
-    if (pass == 0 && tile == 0) { for (uint32_t q = tid; q < OS_SLOT_WORDS; q += THREADS) ghist_other[q] = 0u; }
+    for (uint32_t q = blockIdx.x * THREADS + tid; q < acc_words; q += gridDim.x * THREADS) acc_next[q] = 0u;
+    if (pass == 0 && blockIdx.x == 0) { for (uint32_t q = tid; q < OS_SLOT_WORDS; q += THREADS) ghist_other[q] = 0u; }
     __syncthreads();
+    uint32_t tile = s_tile;
     if (tile >= ntiles) return;                                   // uniform
-    OS_STAMP(0);
     const int shift = 8 * pass;
     int src, dst;
     if (!os_schedule(~s_dead, passes, pass, src, dst)) return;   // uniform: this pass is an identity
     const uint32_t* __restrict__ keys_in = bufs.k[src]; const uint32_t* __restrict__ vals_in = bufs.v[src];
     uint32_t* __restrict__ keys_out = bufs.k[dst]; uint32_t* __restrict__ vals_out = bufs.v[dst];
-
-    const uint32_t tbase = tile * TILE_KEYS;
-    const uint32_t wbase = tbase + w * (64u * ITEMS);
-    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t i = wbase + j * 64u + lane;
-        const bool valid = i < n;
-        key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
-        val[j] = valid ? vals_in[i] : 0u;
-    }
-    const uint32_t digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid);     // overlaps the loads above
-    OS_STAMP(1);
-
-    if (ATOMIC_RANK) {
-        // rank = value returned by an LDS atomic add on the wave's digit counter.  Stable only because the LDS unit serialises the
-        // lanes of one instruction that hit the same counter in ascending lane order — not an architectural promise, so the
-        // library verifies it on the device at context creation (k_lds_order_test) and uses the ballot form below otherwise.
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const bool valid = (wbase + j * 64u + lane) < n;
-            const uint32_t d = ((key[j] - bias) >> shift) & 255u;
-            rank[j] = valid ? atomicAdd(&wcnt[w][d], 1u) : 0u;
-        }
-    } else {
-        const uint64_t lt = (1ull << lane) - 1ull;
-        volatile uint32_t* wc = wcnt[w];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const bool valid = (wbase + j * 64u + lane) < n;
-            const uint32_t d = ((key[j] - bias) >> shift) & 255u;
-            uint64_t m = __ballot(valid);
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bal = __ballot(bit);
-                m &= bit ? bal : ~bal;
-            }
-            rank[j] = 0;
-            if (valid) {
-                const uint32_t c = wc[d];
-                rank[j] = c + (uint32_t)__popcll(m & lt);
-                __builtin_amdgcn_wave_barrier();
-                if ((m & lt) == 0) wc[d] = c + (uint32_t)__popcll(m);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    __syncthreads();
-    // thread d: counts per wave -> offsets inside the tile's digit-d run; tile count of digit d; publish it at once
-    uint32_t cnt = 0;
-    const uint32_t grp = tile / OS_GROUP, sup = grp / OS_SUPER;
+    const uint32_t digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid);
     const uint32_t ngroups = (ntiles + OS_GROUP - 1u) / OS_GROUP, nsuper = (ngroups + OS_SUPER - 1u) / OS_SUPER;
-    if (tid < 256u) {
+
+    while (true) {                                                // uniform: `tile` is the same in every thread
+        OS_STAMP(0);
+        const uint32_t tbase = tile * TILE_KEYS;
+        const uint32_t wbase = tbase + w * (64u * ITEMS);
+        uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 #pragma unroll
-        for (int k = 0; k < WAVES; ++k) { const uint32_t t = wcnt[k][tid]; wcnt[k][tid] = cnt; cnt += t; }
-        __hip_atomic_store(status + (size_t)tile * 256u + tid, os_tword(epoch, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // {arrivals:32, sum:32} accumulators of the group and of the super-group (only those a later tile will read)
-        if (grp + 1u < ngroups) (void)__hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1ull << 32) | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (sup + 1u < nsuper) (void)__hip_atomic_fetch_add(acc + (size_t)(acc_groups + sup) * 256u + tid, (1ull << 32) | (u64)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    OS_STAMP(2);
-    // local run starts, then the reorder inside LDS — none of it needs the other tiles, so it overlaps their publishing
-    const uint32_t lo_ = digit_excl_scan<THREADS>(cnt, s_tmp, tid);
-    if (tid < 256u) loff[tid] = lo_;
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        if ((wbase + j * 64u + lane) < n) {                       // stable: wave-major, item-major, lane order == memory order
-            const uint32_t d = ((key[j] - bias) >> shift) & 255u;
-            const uint32_t l = loff[d] + wcnt[w][d] + rank[j];
-            skeys[l] = key[j];
-            svals[l] = val[j];
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t i = wbase + j * 64u + lane;
+            const bool valid = i < n;
+            key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
+            val[j] = valid ? vals_in[i] : 0u;
         }
-    }
-    OS_STAMP(3);
-    // look back, one memory round trip: the tiles of this group before this one (their words), the groups of this super-group
-    // before this group and the super-groups before this one (their accumulators, complete when every member has arrived)
-    if (tid < 256u) {
-        const uint32_t prefix = os_lookback(status, acc, acc_groups, tile, tid, epoch, err);
-        gpos[tid] = digit_base + prefix;
-    }
-    __syncthreads();
-    OS_STAMP(4);
-    const uint32_t tcount = min(TILE_KEYS, n - tbase);
+        OS_STAMP(1);
+
+        if (ATOMIC_RANK) {
+            // rank = value returned by an LDS atomic add on the wave's digit counter.  Stable only because the LDS unit serialises the
+            // lanes of one instruction that hit the same counter in ascending lane order — not an architectural promise, so the
+            // library verifies it on the device at context creation (k_lds_order_test) and uses the ballot form below otherwise.
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t l = j * THREADS + tid;
-        if (l < tcount) {
-            const uint32_t k = skeys[l];
-            const uint32_t d = ((k - bias) >> shift) & 255u;
-            const uint32_t o = gpos[d] + (l - loff[d]);
-            // streaming stores: the runs go to memory as they are written instead of sitting dirty in this XCD's L2 until the
-            // end-of-kernel write-back (the next pass reads them from other XCDs anyway)
-            __builtin_nontemporal_store(k, keys_out + o);
-            __builtin_nontemporal_store(svals[l], vals_out + o);
+            for (int j = 0; j < ITEMS; ++j) {
+                const bool valid = (wbase + j * 64u + lane) < n;
+                const uint32_t d = ((key[j] - bias) >> shift) & 255u;
+                rank[j] = valid ? atomicAdd(&wcnt[w][d], 1u) : 0u;
+            }
+        } else {
+            const uint64_t lt = (1ull << lane) - 1ull;
+            volatile uint32_t* wc = wcnt[w];
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const bool valid = (wbase + j * 64u + lane) < n;
+                const uint32_t d = ((key[j] - bias) >> shift) & 255u;
+                uint64_t m = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool bit = (d >> b) & 1u;
+                    const uint64_t bal = __ballot(bit);
+                    m &= bit ? bal : ~bal;
+                }
+                rank[j] = 0;
+                if (valid) {
+                    const uint32_t c = wc[d];
+                    rank[j] = c + (uint32_t)__popcll(m & lt);
+                    __builtin_amdgcn_wave_barrier();
+                    if ((m & lt) == 0) wc[d] = c + (uint32_t)__popcll(m);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
+        __syncthreads();
+        // thread d: counts per wave -> offsets inside the tile's digit-d run; tile count of digit d; publish it at once
+        uint32_t cnt = 0;
+        uint32_t garr = 0;
+        const uint32_t grp = tile / OS_GROUP, sup = grp / OS_SUPER;
+        if (tid < 256u) {
+#pragma unroll
+            for (int k = 0; k < WAVES; ++k) { const uint32_t t = wcnt[k][tid]; wcnt[k][tid] = cnt; cnt += t; }
+            __hip_atomic_store(status + (size_t)tile * 256u + tid, os_tword(epoch, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // {arrivals:8, sum:24} accumulator of the group (only if a later tile will read it); what it held before comes back after the
+            // reorder below
+            if (grp + 1u < ngroups) garr = __hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1u << 24) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        OS_STAMP(2);
+        // local run starts, then the reorder inside LDS — none of it needs the other tiles, so it overlaps their publishing
+        const uint32_t lo_ = digit_excl_scan<THREADS>(cnt, s_tmp, tid);
+        if (tid < 256u) loff[tid] = lo_;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if ((wbase + j * 64u + lane) < n) {                   // stable: wave-major, item-major, lane order == memory order
+                const uint32_t d = ((key[j] - bias) >> shift) & 255u;
+                const uint32_t l = loff[d] + wcnt[w][d] + rank[j];
+                skeys[l] = key[j];
+                svals[l] = val[j];
+            }
+        }
+        OS_STAMP(3);
+        if (tid < 256u) {
+            // the tile that completes its group (per digit: whichever arrived sixteenth) hands the group's total to the super-group: a
+            // super-group's accumulator takes OS_SUPER additions per digit, not one from every tile under it
+            if (sup + 1u < nsuper && (garr >> 24) == OS_GROUP - 1u)
+                (void)__hip_atomic_fetch_add(acc + (size_t)(acc_groups + sup) * 256u + tid, (1u << 24) | ((garr & 0xFFFFFFu) + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // look back, one memory round trip: the tiles of this group before this one (their words), the groups of this super-group
+            // before this group and the super-groups before this one (their accumulators, complete when every member has arrived)
+            const uint32_t prefix = os_lookback(status, acc, acc_groups, tile, tid, epoch, err);
+            gpos[tid] = digit_base + prefix;
+        }
+        __syncthreads();
+        OS_STAMP(4);
+        const uint32_t tcount = min(TILE_KEYS, n - tbase);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint32_t l = j * THREADS + tid;
+            if (l < tcount) {
+                const uint32_t k = skeys[l];
+                const uint32_t d = ((k - bias) >> shift) & 255u;
+                const uint32_t o = gpos[d] + (l - loff[d]);
+                // Small sorts (one round of tiles): streaming stores, the runs go to memory as they are written instead of sitting dirty in
+                // this XCD's L2 until the end-of-kernel write-back.  Large sorts (the 8192-key shape, several rounds of tiles per workgroup):
+                // ordinary stores, so that the L2 merges the partial lines at the ends of neighbouring runs before they reach HBM — measured
+                // at 10^7 keys: 75.7 -> 57.7 us per pass; at 10^6 keys the streaming form is the faster one (14.1 against 15.8).
+                if (ITEMS >= 16) { keys_out[o] = k; vals_out[o] = svals[l]; }
+                else { __builtin_nontemporal_store(k, keys_out + o); __builtin_nontemporal_store(svals[l], vals_out + o); }
+            }
+        }
+        OS_STAMP(5);
+        // The next ticket is drawn only now, behind the write-out: tiles with later tickets wait for the tile it names to publish, so a
+        // ticket must not be held while its holder is still busy with something else (drawn before the write-out, 8 us at 10^7 keys, every
+        // successor's look-back waited that long).  The other workgroup of the CU covers the round trip.
+        uint32_t next = 0;
+        if (tid == 0) next = atomicAdd(ticket, 1u);
+        __syncthreads();                                          // everybody is done with the tile's LDS
+        if (tid == 0) s_tile = next;
+        for (uint32_t q = tid; q < WAVES * 256u; q += THREADS) (&wcnt[0][0])[q] = 0u;
+        __syncthreads();
+        tile = s_tile;
+        if (tile >= ntiles) return;                               // uniform; every workgroup ends on a ticket past the last tile
     }
-    OS_STAMP(5);
 }
 
 // Does an LDS atomic add executed by a whole wave return, to the lanes that hit the same address, their rank in ascending lane order?
@@ -531,6 +556,15 @@ template <int THREADS, int ITEMS, bool ATOMIC_RANK>
 static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist) {
     const uint32_t tile_keys = THREADS * ITEMS;
     const uint32_t tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
+    // persistent workgroups: as many as the device holds at once (asked of the runtime once per shape)
+    static uint32_t resident = 0;
+    if (!resident) {
+        int per_cu = 0, dev = 0; hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_os_pass<THREADS, ITEMS, ATOMIC_RANK>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
+        resident = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+    }
+    const uint32_t grid = std::min(tiles, resident);
     uint32_t* ghist = s.hist + (s.flip ? OS_SLOT_WORDS : 0);
     uint32_t* ghist_other = s.hist + (s.flip ? 0 : OS_SLOT_WORDS);
     hipError_t e;
@@ -555,7 +589,7 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     // accumulator sets sit behind the tile words of the LARGEST sort this scratch was sized for (so they never move between launches)
     const size_t cap_tiles = (s.cap + 1023) / 1024, cap_groups = cap_tiles / OS_GROUP + 2, cap_supers = cap_groups / OS_SUPER + 2;
     const size_t acc_words = (cap_groups + cap_supers) * 256;
-    u64* acc_base = reinterpret_cast<u64*>(status + (cap_tiles + 2) * 256);
+    uint32_t* acc_base = status + (cap_tiles + 2) * 256;
     OsBufs b;
     b.k[0] = keys; b.v[0] = vals;
     b.k[1] = s.keys2; b.v[1] = s.vals2;
@@ -566,10 +600,9 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
             if ((e = hipMemsetAsync(status, 0, (s.hist_cap - 2 * OS_SLOT_WORDS) * 4, st)) != hipSuccess) return e;
             ++s.epoch;
         }
-        k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(tiles), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, acc_base + (s.acc_flip ? acc_words : 0), acc_base + (s.acc_flip ? 0 : acc_words), (uint32_t)cap_groups, (uint32_t)acc_words,
+        k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(grid), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, acc_base + (s.acc_flip ? acc_words : 0), acc_base + (s.acc_flip ? 0 : acc_words), (uint32_t)cap_groups, (uint32_t)acc_words,
                                                                          s.epoch & 0x3FFFFFFFu,
-                                                                         s.err ? s.err : s.totals, s.totals + 64, s.ticket_base, bias, (stampf && p == stamp_pass) ? stamps : nullptr);
-        s.ticket_base += tiles;               // every workgroup of the launch draws exactly one ticket
+                                                                         s.err ? s.err : s.totals, s.totals + 64 + (s.acc_flip ? 1 : 0), s.totals + 64 + (s.acc_flip ? 0 : 1), bias, (stampf && p == stamp_pass) ? stamps : nullptr);
         s.acc_flip ^= 1;
     }
     if (stampf && stamps) {   // tuning aid: dump per-tile wall-clock stamps (100 MHz) of one pass
@@ -590,7 +623,7 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
     if (e != hipSuccess) return e;
     int passes = (key_bits + 7) / 8;
     if (passes < 2) passes = 2;                       // an even number of executed passes always exists (see os_schedule)
-    const int shape = s.shape_knob ? s.shape_knob : (n <= ((size_t)3 << 20) ? 2 : 5);     // 4096-key tiles for small sorts, 8192-key tiles beyond
+    const int shape = s.shape_knob ? s.shape_knob : (n <= ((size_t)3 << 19) ? 2 : 5);     // 4096-key tiles for small sorts, 8192-key tiles beyond (measured cross-over: 1.5M keys)
     const bool atomic_rank = s.rank_knob ? s.rank_knob == 2 : s.atomic_rank;
 #define GS4D_OS(T, I) (atomic_rank ? onesweep<T, I, true>(st, s, keys, vals, n, n_dev, passes, have_hist) : onesweep<T, I, false>(st, s, keys, vals, n, n_dev, passes, have_hist))
     switch (shape) {

@@ -24,8 +24,7 @@ def reset():
     hip.hipMemcpy(C.c_void_p(pv), C.c_void_p(pv0), C.c_size_t(4 * n), 3)
     hip.hipDeviceSynchronize()
 for _ in range(5):
-    reset(); ctx.sort_pairs(kb, vb, n)
-ctx.finish()
+    reset(); ctx.sort_pairs(kb, vb, n); ctx.finish()      # the lanes' streams do not synchronise with the null stream reset() copies on
 # sorted input is a different (friendlier) key distribution per pass, so re-randomise between timed sorts but time only the sorts
 ts = []
 for _ in range(reps):

@@ -2,8 +2,8 @@
 # usage: tools/sort_prof.sh <tag> [env...]   -> prints per-kernel averages of the sort micro-benchmark under rocprofv3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1; shift
-env "$@" true
-( export "$@"; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sp_$tag -- python3 tools/sort_bench.py 1000000 40 depth > /dev/null 2>&1 )
+env "$@" true > /dev/null
+( export "$@"; rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sp_$tag -- python3 tools/sort_bench.py ${SORT_N:-1000000} ${SORT_REPS:-40} depth > /dev/null 2>&1 )
 python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/sp_$tag/*/*kernel_stats.csv")[0]
