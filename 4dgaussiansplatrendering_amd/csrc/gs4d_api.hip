@@ -383,7 +383,8 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             const PreOut po = { L.proj, L.rects };
             TileCount tc;
             if (v2) { tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.rows = L.tl.rows; tc.tiles_x = c->tiles_x; tc.shard_rank = c->shard_rank; tc.shard_world = c->shard_world; tc.ks = a.ks; }
-            if (v2 && a.fuse) {
+            if (a.fuse) {
+                tc.ks = a.ks;
                 Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
                 if (!K || !I) return fail(c, GS4D_E_INVALID, "draw: the key buffers of the queued key generation have been deleted");
                 hipError_t he = hipSuccess;
@@ -398,6 +399,13 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
         }
         L.proj_n = npre;
         { int rc = fb_access(c, F); if (rc) return rc; }
+        if (a.fuse && !v2) {
+            // ordered path: the sort the application asked for runs here, between the projection (which wrote its keys and digit
+            // histograms) and the binning (which reads the sorted index)
+            Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
+            StageTimer t(c, GS4D_T_SORT);
+            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true));
+        }
     }
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
@@ -913,9 +921,15 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     if (c->po.keygen) {
         // a queued key generation + sort: executed by this draw if it is the draw they were made for (it takes its blend order from exactly
         // that sort, on the same lane, and the unordered path can run), else launched on their own first
-        const bool mine = a.v2 && a.mode == GS4D_MODE_4D_SORTED && !a.quads && c->po.sorted && c->po.idx == a.order && c->po.data == a.data && c->po.lane == c->cur
-                       && tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, c->slabs, a.keybits);
-        if (mine) { a.fuse = true; a.fuse_keys = c->po.keys; a.fuse_idx = c->po.idx; a.fuse_span = c->po.span; c->po.keygen = c->po.sorted = false; c->stat_fused++; }
+        const Buffer* pd = getbuf(c, a.data);
+        bool mine = a.mode == GS4D_MODE_4D_SORTED && !a.quads && c->po.sorted && c->po.idx == a.order && c->po.data == a.data && c->po.lane == c->cur
+                 && pd && a.instances == c->po.n && pd->bytes / 96 == c->po.n;
+        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, c->slabs, a.keybits)) a.v2 = false;
+        if (mine) {
+            // on the ordered path too: the projection writes the keys, the sort follows it, the binning reads the sorted index
+            if (!a.v2) { a.ks = lane(c).kg_ks; a.keybits = lane(c).kg_bits; }
+            a.fuse = true; a.fuse_keys = c->po.keys; a.fuse_idx = c->po.idx; a.fuse_span = c->po.span; c->po.keygen = c->po.sorted = false; c->stat_fused++;
+        }
         else { int rc2 = flush_order(c); if (rc2) return rc2; }
     }
     const size_t before = L.proj_n;

@@ -314,14 +314,16 @@ __global__ __launch_bounds__(256) void k_preprocess(SRC src, uint32_t n, PU u, P
     (void)project_record(src, n, i, u, out, tc.ks, key);
 }
 
-// Unordered path: workgroup w walks records [w * seg, (w + 1) * seg), SEG_THREADS per round, and leaves the counts of its segment per bucket.
+// Unordered path (COUNT): workgroup w walks records [w * seg, (w + 1) * seg), SEG_THREADS per round, and leaves the counts of its segment
+// per bucket.
 // FUSE_KEYS: it is also k_keygen (sort.hip) for these records — the key it derives the blend order from IS the depth key: written to the
-// caller's key buffer with the identity index beside it, bounds-checked, and counted into the depth sort's digit histograms.
-template <class SRC, bool FUSE_KEYS>
+// caller's key buffer with the identity index beside it, bounds-checked, and counted into the depth sort's digit histograms.  Without
+// COUNT that is all it adds to the projection: the ordered path's form (the sort follows, then binning.hip reads the sorted index).
+template <class SRC, bool FUSE_KEYS, bool COUNT>
 __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t n, PU u, PreOut out, TileCount tc) {
-    __shared__ uint32_t h[1024];
+    __shared__ uint32_t h[COUNT ? 1024 : 1];
     __shared__ uint32_t kh[FUSE_KEYS ? OS_MAX_PASSES : 1][256];
-    for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) h[b] = 0u;
+    if (COUNT) for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) h[b] = 0u;
     if (FUSE_KEYS && threadIdx.x < 256u) os_hist_clear(kh, threadIdx.x);
     __syncthreads();
     const uint32_t i0 = blockIdx.x * tc.seg, i1 = min(n, i0 + tc.seg);
@@ -331,8 +333,10 @@ __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t
         uint32_t key = 0u;
         if (i < i1) {
             const uint2 rect = project_record(src, n, i, u, out, tc.ks, key);
-            tc.skey[i] = key;
-            r = tile_rect(rect.x, rect.y, (uint32_t)tc.shard_rank, (uint32_t)tc.shard_world);
+            if (COUNT) {
+                tc.skey[i] = key;
+                r = tile_rect(rect.x, rect.y, (uint32_t)tc.shard_rank, (uint32_t)tc.shard_world);
+            }
             if (FUSE_KEYS) {
                 tc.keys_out[i] = __uint_as_float(key + tc.ks.bias);          // the blend key is the depth key's bit pattern relative to the bias
                 tc.idx_out[i] = i;
@@ -340,10 +344,10 @@ __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t
             }
         }
         if (FUSE_KEYS) os_hist_add(kh, key, i < i1, OS_MAX_PASSES);
-        count_buckets(h, tc.nb - 1u, (uint32_t)tc.tiles_x, r);
+        if (COUNT) count_buckets(h, tc.nb - 1u, (uint32_t)tc.tiles_x, r);
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) tc.hist[(size_t)b * tc.rows + blockIdx.x] = h[b];       // one row per bucket: k_bucket_scan scans along the segments
+    if (COUNT) for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) tc.hist[(size_t)b * tc.rows + blockIdx.x] = h[b];       // one row per bucket: k_bucket_scan scans along the segments
     if (FUSE_KEYS && threadIdx.x < 256u) os_hist_flush(kh, tc.ghist, OS_MAX_PASSES, threadIdx.x);
 }
 
@@ -357,8 +361,14 @@ static PU make_pu(const Uniforms& un, int W, int H) {
 template <class SRC>
 static hipError_t launch_pre(hipStream_t st, SRC src, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
     if (n == 0) return hipSuccess;
-    if (tc.hist && tc.keys_out) k_project_count<SRC, true><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
-    else if (tc.hist) k_project_count<SRC, false><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    if (tc.hist && tc.keys_out) k_project_count<SRC, true, true><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    else if (tc.hist) k_project_count<SRC, false, true><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    else if (tc.keys_out) {
+        // segments sized so that at most 2048 workgroups flush digit histograms (1024 global atomics each)
+        TileCount t2 = tc;
+        t2.seg = (uint32_t)std::max<size_t>(4096, (((n + 2047) / 2048) + SEG_THREADS - 1) / SEG_THREADS * SEG_THREADS);
+        k_project_count<SRC, true, false><<<dim3((unsigned)((n + t2.seg - 1) / t2.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, t2);
+    }
     else k_preprocess<SRC><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }

@@ -387,8 +387,9 @@ def _expected_frame(oracle, rec, t, cam, view, proj, W, H, viewz):
     return ekeys.view(np.uint32), skeys, eperm, eproj
 
 
+@pytest.mark.parametrize("path", ["auto", "ordered"])
 @pytest.mark.parametrize("key_mode", ["euclid", "view_z"])
-def test_draw_that_generates_its_own_depth_keys(gs4d, oracle, monkeypatch, key_mode):
+def test_draw_that_generates_its_own_depth_keys(gs4d, oracle, monkeypatch, key_mode, path):
     n, W, H = 120000, 1280, 720
     pos4, q, sc, life, fade, vel, rgba = scenes.cube_params_4d(n, seed=47)
     rec = gs4d.build_records_4d(pos4, q, sc * 2.0, life, fade, vel, rgba)
@@ -399,11 +400,11 @@ def test_draw_that_generates_its_own_depth_keys(gs4d, oracle, monkeypatch, key_m
     km = None if key_mode == "euclid" else gs4d.KEY_VIEW_Z
     res = {}
     for fuse in (1, 0):
-        ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_FUSE_KEYGEN=fuse)
+        ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_FUSE_KEYGEN=fuse, **({"GS4D_DRAW_PATH": "ordered"} if path == "ordered" else {}))
         res[fuse], st = _frames_with_late_reads(ctx, gs4d, rec, cams, W, H, km)
         ctx.close()
         assert st["fused_keygen_draws"] == (len(cams) if fuse else 0)
-        assert st["unordered_draws"] == len(cams)
+        assert st["unordered_draws"] == (len(cams) if path == "auto" else 0)
     for k, cam in enumerate(cams):
         view, proj = cam_mats(gs4d, cam, W, H)
         _, skeys, eperm, eproj = _expected_frame(oracle, rec, 0.25 * k, cam, view, proj, W, H, km is not None)
