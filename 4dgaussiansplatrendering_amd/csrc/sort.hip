@@ -339,7 +339,8 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     if (!os_schedule(~s_dead, passes, pass, src, dst)) return;   // uniform: this pass is an identity
     const uint32_t* __restrict__ keys_in = bufs.k[src]; const uint32_t* __restrict__ vals_in = bufs.v[src];
     uint32_t* __restrict__ keys_out = bufs.k[dst]; uint32_t* __restrict__ vals_out = bufs.v[dst];
-    const uint32_t digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid);
+    uint32_t digit_base = 0;
+    bool first = true;
     const uint32_t ngroups = (ntiles + OS_GROUP - 1u) / OS_GROUP, nsuper = (ngroups + OS_SUPER - 1u) / OS_SUPER;
 
     while (true) {                                                // uniform: `tile` is the same in every thread
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
             key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
             val[j] = valid ? vals_in[i] : 0u;
         }
+        if (first) { digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid); first = false; }      // once per workgroup, under the first tile's loads
         OS_STAMP(1);
 
         if (ATOMIC_RANK) {
@@ -401,7 +403,9 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
             __hip_atomic_store(status + (size_t)tile * 256u + tid, os_tword(epoch, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // {arrivals:8, sum:24} accumulator of the group (only if a later tile will read it); what it held before comes back after the
             // reorder below
-            if (grp + 1u < ngroups) garr = __hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1u << 24) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (asked for only where a super-group total will be needed: waiting for the returned value costs a memory round trip)
+            if (sup + 1u < nsuper) garr = __hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1u << 24) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (grp + 1u < ngroups) (void)__hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1u << 24) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         OS_STAMP(2);
         // local run starts, then the reorder inside LDS — none of it needs the other tiles, so it overlaps their publishing
@@ -450,6 +454,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         // The next ticket is drawn only now, behind the write-out: tiles with later tickets wait for the tile it names to publish, so a
         // ticket must not be held while its holder is still busy with something else (drawn before the write-out, 8 us at 10^7 keys, every
         // successor's look-back waited that long).  The other workgroup of the CU covers the round trip.
+        if (gridDim.x >= ntiles) return;                          // uniform: every tile has a workgroup of its own, nothing is left to draw
         uint32_t next = 0;
         if (tid == 0) next = atomicAdd(ticket, 1u);
         __syncthreads();                                          // everybody is done with the tile's LDS

@@ -227,8 +227,9 @@ bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slab
     uint32_t nb = 64;
     while (((size_t)nb * 256 < ntiles || (size_t)nb * 8192 < nrecords + nrecords / 2) && nb < 1024) nb *= 2;
     if ((size_t)nb * 256 < ntiles) return false;
-    // segments of >= 4096 records (longer runs per bucket, a small count matrix), at most 1024 of them (k_bucket_scan keeps a bucket's counts in registers)
-    size_t rows = std::min<size_t>((nrecords + 4095) / 4096, 1024);
+    // segments of >= 2048 records (at 10^6 records 4096 left the projection with 245 workgroups = 8 waves per CU in flight: 44.6 us; longer
+    // segments mean longer runs per bucket and a smaller count matrix), at most 1024 of them (k_bucket_scan keeps a bucket's counts in registers)
+    size_t rows = std::min<size_t>((nrecords + 2047) / 2048, 1024);
     size_t seg = ((nrecords + rows - 1) / rows + SEG_THREADS - 1) / SEG_THREADS * SEG_THREADS;
     rows = (nrecords + seg - 1) / seg;
     if (slabs < 1) slabs = 1;

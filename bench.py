@@ -37,8 +37,9 @@ SWEEP_FRAMES = 256          # BASELINE.json configs[3]
 PROFILE_TAG = "r02"         # profiles/<tag>_pmc_traffic_c{2,3}.json hold the per-launch HBM traffic of this build's kernels
 
 # stage -> (kernel the stage is made of, launches per frame); "sort" and "pairsort" launch counts come from the library's stats
-KERNELS = {"keygen": "gs4d::k_keygen", "sort": "gs4d::k_os_pass", "preprocess": "gs4d::k_preprocess", "binning": "gs4d::k_bucket_scatter",
+KERNELS = {"keygen": "gs4d::k_keygen", "sort": "gs4d::k_os_pass", "preprocess": "gs4d::k_project_count", "binning": "gs4d::k_bucket_scatter",
            "pairsort": "gs4d::k_os_pass", "composite": "gs4d::k_composite_v2"}
+KERNELS_ORDERED = dict(KERNELS, binning="gs4d::k_bin_emit", composite="gs4d::k_composite<")       # the instance-ordered path (long tile lists: configs[2])
 
 
 def algorithmic_bytes(n, w, h):
@@ -123,7 +124,7 @@ def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file):
         return None
     credited = max(timed, key=timed.get)
     launches = {"sort": gs4d_stats["depth_sort_passes"], "pairsort": max(1, gs4d_stats["tile_sort_passes"])}.get(credited, 1)
-    kname = KERNELS[credited]
+    kname = (KERNELS_ORDERED if gs4d_stats["tile_sort_passes"] > 0 else KERNELS)[credited]
     ach = alg[credited] / (timed[credited] * 1e-3) / 1e9
     frame_ach = alg["frame"] / (ms_per_step * 1e-3) / 1e9
     traffic, tsrc = None, None
@@ -133,7 +134,7 @@ def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file):
         if hit:
             traffic, tsrc = hit[0]["hbm_bytes_per_launch"], os.path.relpath(traffic_file, ROOT)
     warm = {k: v for k, v in warm_ms.items() if v > 0}
-    return {"bound": "hbm", "kernel": kname, "stage": credited, "launches_per_frame": launches,
+    return {"bound": "hbm", "kernel": kname.rstrip("<"), "stage": credited, "launches_per_frame": launches,
             "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
             "traffic": traffic, "traffic_source": tsrc,
             "kernel_ms": round(timed[credited] / launches, 5), "algorithmic_bytes_per_launch": alg[credited] // launches,
@@ -188,7 +189,7 @@ def main():
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the line reports the median window")
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: frames of every rank per RCCL gather")
-    ap.add_argument("--lanes", type=int, default=None, help="frame lanes of the context (default: the library's, 2); experiments")
+    ap.add_argument("--lanes", type=int, default=None, help="frame lanes of the context (default: the library's, 4); experiments")
     ap.add_argument("--keybufs", type=int, default=None, help="key / sort-index buffer pairs the application cycles through (default: one per lane)")
     ap.add_argument("--no-c3", action="store_true", help="N=1: skip the configs[2] block (10^7 splats)")
     ap.add_argument("--no-latency", action="store_true", help="N=1: skip the one-lane frame time")
