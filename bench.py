@@ -144,6 +144,20 @@ def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file):
             "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
 
 
+def alone_block(roofline, one, n):
+    """The credited kernel with nothing beside it: the same HIP-event timing taken in the one-lane run (frames do not overlap there)."""
+    if not roofline:
+        return
+    stage, launches = roofline["stage"], roofline["launches_per_frame"]
+    ms = one["warm_ms"].get(stage, -1.0)
+    if ms <= 0:
+        return
+    ach = algorithmic_bytes(n, W, H)[stage] / (ms * 1e-3) / 1e9
+    roofline["alone"] = {"kernel_ms": round(ms / launches, 5), "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5),
+                         "note": "same kernel, same events, one frame lane: no other kernel runs beside it",
+                         "stage_ms_one_lane": {k: round(v, 5) for k, v in one["warm_ms"].items()}}
+
+
 def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None, keybufs=4):
     """One GPU, static 3D splats in the cube (configs[1] / configs[2]).  Returns (result dict, records)."""
     cam = scenes.CAM_CUBE
@@ -229,6 +243,7 @@ def single_gpu(args, gs4d, scenes, device):
     if not args.no_latency:
         one, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=1)
         latency = round(one["ms_per_step"], 5)
+        alone_block(roofline, one, n)
     c3 = None
     if not args.no_c3 and n == 1_000_000:
         n3 = 10_000_000
@@ -237,6 +252,10 @@ def single_gpu(args, gs4d, scenes, device):
               "ms_per_step": r3["ms_per_step"], "value": r3["value"], "unit": "splats/s", "windows_ms_per_step": r3["windows_ms_per_step"],
               "tile_list_entries": r3["stats"]["entries"], "longest_tile_list": r3["stats"]["longest_list"], "unordered_draws": r3["stats"]["unordered_draws"],
               "roofline": roofline_block(r3["stats"], r3["stage_ms"], r3["warm_ms"], n3, r3["ms_per_step"], os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_c3.json"))}
+        if not args.no_latency:
+            one3, _, _ = measure_single(gs4d, scenes, n3, 10, 5, 3, device, stage_events=False, lanes=1)
+            c3["latency_ms_one_lane"] = round(one3["ms_per_step"], 5)
+            alone_block(c3["roofline"], one3, n3)
     cpu = None if args.no_cpu_baseline else cpu_baseline(rec, cam, view, proj)
     st = res["stats"]
     return {
