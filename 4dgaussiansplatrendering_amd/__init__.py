@@ -17,8 +17,11 @@ LIB_PATH = os.path.join(_HERE, "libgs4d.so")
 MODE_4D_SORTED, MODE_4D_DIRECT, MODE_3D_FULL, MODE_2D = 0, 1, 2, 3
 U_TIME, U_MIN_OPACITY = 0, 1
 U_VIEW, U_PROJ = 0, 1
+# glBlendFunc factors (GL enum values): the reference's blend menu, DebugMenus.h:41-59
+ZERO, ONE, SRC_COLOR, ONE_MINUS_SRC_COLOR, SRC_ALPHA, ONE_MINUS_SRC_ALPHA = 0, 1, 0x0300, 0x0301, 0x0302, 0x0303
+DST_ALPHA, ONE_MINUS_DST_ALPHA, DST_COLOR, ONE_MINUS_DST_COLOR = 0x0304, 0x0305, 0x0306, 0x0307
+CONSTANT_COLOR, ONE_MINUS_CONSTANT_COLOR, CONSTANT_ALPHA, ONE_MINUS_CONSTANT_ALPHA = 0x8001, 0x8002, 0x8003, 0x8004
 KEY_REF_INV_EUCLID, KEY_VIEW_Z = 0, 1
-SRC_ALPHA, ONE_MINUS_SRC_ALPHA = 0x0302, 0x0303
 STAGES = ("keygen", "sort", "preprocess", "binning", "pairsort", "composite")
 CLEAR_COLOR = (0.18431373, 0.20784314, 0.25882353, 1.0)   # Application.cpp:125
 

@@ -62,10 +62,10 @@ hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, int W, int H
     return hipGetLastError();
 }
 
-template <bool PREMULT_C>
+template <bool PREMULT_C, bool GENERAL>
 __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ proj, const uint32_t* __restrict__ pair_vals, uint32_t* __restrict__ ranges,
                                                   const uint32_t* __restrict__ total, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
-                                                  float4* __restrict__ fb, int dbg_arg) {
+                                                  float4* __restrict__ fb, int dbg_arg, BlendFn bf) {
 #ifdef GS4D_TUNING
     const int dbg = dbg_arg;             // GS4D_COMPOSITE_DBG: tuning builds only (make TUNING=1)
 #else
@@ -83,6 +83,20 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
     if (lane < 2u && end != 0u) ranges[2 * tile + lane] = 0u;      // leave the table all-zero for the next draw (no memset launch)
 
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
+    if (GENERAL) {
+        // a blend function other than the default: no transmittance form — the pixel's value is taken through the list in draw order
+        const bool in = px < W && py < H;
+        const size_t o = in ? (size_t)py * W + px : 0;
+        const float4 d = (fb_is_clear || !in) ? clear : fb[o];
+        Cr = d.x; Cg = d.y; Cb = d.z; A = d.w;
+        for (uint32_t lo = start; lo < end; lo += 64u) {
+            const uint32_t cnt = min(64u, end - lo);
+            const uint32_t rec = lane < cnt ? pair_vals[lo + lane] : 0u;         // lane s holds list entry lo+s: s = 0 is drawn first
+            composite_chunk<PREMULT_C, true>(proj, rec, cnt, lane, tx0, ty0, fx, fy, stage, pmask, dbg, T, Cr, Cg, Cb, A, bf);
+        }
+        if (in) fb[o] = make_float4(Cr, Cg, Cb, A);
+        return;
+    }
     for (uint32_t hi = end; hi > start;) {
         const uint32_t cnt = min(64u, hi - start);
         // lane s holds list entry hi-1-s : s = 0 is the LAST (front-most) entry of this chunk
@@ -99,7 +113,7 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
 }
 
 hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
-                            int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb) {
+                            int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb, int blend_src, int blend_dst) {
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid((unsigned)(tiles_x * tiles_y));
 #ifdef GS4D_TUNING
@@ -107,8 +121,14 @@ hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* 
 #else
     const int dbg = 0;
 #endif
-    if (premult_c) k_composite<true><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg);
-    else           k_composite<false><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg);
+    const BlendFn bf{ blend_src, blend_dst };
+    const bool general = !(blend_src == GS4D_SRC_ALPHA && blend_dst == GS4D_ONE_MINUS_SRC_ALPHA);
+    if (general) {
+        if (premult_c) k_composite<true, true><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg, bf);
+        else           k_composite<false, true><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg, bf);
+    }
+    else if (premult_c) k_composite<true, false><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg, bf);
+    else                k_composite<false, false><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg, bf);
     return hipGetLastError();
 }
 

@@ -14,11 +14,45 @@ namespace gs4d {
 // Entries whose box covers more than SMALL_AREA pixels of the tile are always tested pixel-parallel.
 constexpr int SMALL_AREA = 16;
 
-template <bool PREMULT_C>
-__device__ __forceinline__ void blend_fragment(float u, float v, float alpha, float r_, float g_, float b_, float& T, float& Cr, float& Cg, float& Cb, float& A) {
+// glBlendFunc factors (GL enum values; the set the reference's menu offers, DebugMenus.h:41-59).  The reference never calls glBlendColor:
+// the blend colour stays (0, 0, 0, 0), so CONSTANT_* = 0 and ONE_MINUS_CONSTANT_* = 1.
+struct BlendFn { int sf, df; };
+__device__ __forceinline__ float blend_factor(int f, float sc, float sa, float dc, float da) {
+    switch (f) {
+    case GS4D_ONE: case GS4D_ONE_MINUS_CONSTANT_COLOR: case GS4D_ONE_MINUS_CONSTANT_ALPHA: return 1.0f;
+    case GS4D_SRC_COLOR: return sc;
+    case GS4D_ONE_MINUS_SRC_COLOR: return 1.0f - sc;
+    case GS4D_SRC_ALPHA: return sa;
+    case GS4D_ONE_MINUS_SRC_ALPHA: return 1.0f - sa;
+    case GS4D_DST_ALPHA: return da;
+    case GS4D_ONE_MINUS_DST_ALPHA: return 1.0f - da;
+    case GS4D_DST_COLOR: return dc;
+    case GS4D_ONE_MINUS_DST_COLOR: return 1.0f - dc;
+    default: return 0.0f;                                  // GS4D_ZERO, GS4D_CONSTANT_COLOR, GS4D_CONSTANT_ALPHA
+    }
+}
+// dst = clamp(src * S + dst * D) on all four channels (OpenGL 4.4, 17.3.8: FUNC_ADD, fixed-point framebuffer; src is already clamped)
+__device__ __forceinline__ void blend_general(BlendFn bf, float sr, float sg, float sb, float sa, float& dr, float& dg, float& db, float& da) {
+    const float r = __saturatef(__fadd_rn(__fmul_rn(sr, blend_factor(bf.sf, sr, sa, dr, da)), __fmul_rn(dr, blend_factor(bf.df, sr, sa, dr, da))));
+    const float g = __saturatef(__fadd_rn(__fmul_rn(sg, blend_factor(bf.sf, sg, sa, dg, da)), __fmul_rn(dg, blend_factor(bf.df, sg, sa, dg, da))));
+    const float b = __saturatef(__fadd_rn(__fmul_rn(sb, blend_factor(bf.sf, sb, sa, db, da)), __fmul_rn(db, blend_factor(bf.df, sb, sa, db, da))));
+    const float a = __saturatef(__fadd_rn(__fmul_rn(sa, blend_factor(bf.sf, sa, sa, da, da)), __fmul_rn(da, blend_factor(bf.df, sa, sa, da, da))));
+    dr = r; dg = g; db = b; da = a;
+}
+
+// GENERAL = false: the default function (SRC_ALPHA, ONE_MINUS_SRC_ALPHA), accumulated front to back: colour C, transmittance T.
+// GENERAL = true : any function of the menu, applied fragment by fragment in draw order to the pixel's value (Cr, Cg, Cb, A); T unused.
+template <bool PREMULT_C, bool GENERAL = false>
+__device__ __forceinline__ void blend_fragment(float u, float v, float alpha, float r_, float g_, float b_, float& T, float& Cr, float& Cg, float& Cb, float& A, BlendFn bf = BlendFn{ 0, 0 }) {
     const float q = u * u + v * v;
     const float cg = __expf(-32.0f * q);
     if (cg >= 0.0001f) {                                   // Splat4DFragShader.GLSL:30 discard
+        if (GENERAL) {
+            const float al = __saturatef(alpha * cg);
+            if (PREMULT_C) { r_ = __saturatef(r_ * cg); g_ = __saturatef(g_ * cg); b_ = __saturatef(b_ * cg); }
+            blend_general(bf, r_, g_, b_, al, Cr, Cg, Cb, A);
+            return;
+        }
         // The reference blends into a fixed-point (RGBA8) framebuffer: the GL clamps the fragment's colour and alpha to [0, 1] before the
         // blend (OpenGL 4.4, 17.3.8).  Colours that are not premultiplied were clamped once per record by the projection kernel.
         const float al = __saturatef(alpha * cg);
@@ -31,9 +65,10 @@ __device__ __forceinline__ void blend_fragment(float u, float v, float alpha, fl
 
 // One chunk of the tile's list, front to back: lane s < cnt carries record `rec` of list entry (end of chunk - 1 - s), so s = 0 is the
 // front-most entry.  stage: 64 x 3 float4, pmask: 64 x 2 words (per pixel: 64-bit mask of the chunk entries that cover it).
-template <bool PREMULT_C>
+// GENERAL: the chunk is walked in DRAW order instead — lane s carries list entry (start of chunk + s).
+template <bool PREMULT_C, bool GENERAL = false>
 __device__ __forceinline__ void composite_chunk(const float4* __restrict__ proj, uint32_t rec, uint32_t cnt, uint32_t lane, int tx0, int ty0, float fx, float fy,
-                                                float4* stage, uint32_t* pmask, int dbg, float& T, float& Cr, float& Cg, float& Cb, float& A) {
+                                                float4* stage, uint32_t* pmask, int dbg, float& T, float& Cr, float& Cg, float& Cb, float& A, BlendFn bf = BlendFn{ 0, 0 }) {
     // lane s holds list entry hi-1-s : s = 0 is the LAST (front-most) entry of this chunk
     int lx0 = 0, ly0 = 0, bw = 0, area = 0;
     float4 ra = make_float4(0, 0, 0, 0), rb = ra;
@@ -66,7 +101,7 @@ __device__ __forceinline__ void composite_chunk(const float4* __restrict__ proj,
             const bool cov = fabsf(u) <= 0.5f && fabsf(v) <= 0.5f;
             if (__ballot(cov) == 0ull) continue;
             const float4 c = stage[s * 3 + 2];          // g, b, -, -
-            if (cov) blend_fragment<PREMULT_C>(u, v, b.z, b.w, c.x, c.y, T, Cr, Cg, Cb, A);
+            if (cov) blend_fragment<PREMULT_C, GENERAL>(u, v, b.z, b.w, c.x, c.y, T, Cr, Cg, Cb, A, bf);
         }
     } else {
         // ---- phase A (lane = entry): mark the covered pixels of small footprints ----
@@ -108,7 +143,7 @@ __device__ __forceinline__ void composite_chunk(const float4* __restrict__ proj,
                 const float dx = __fsub_rn(fx, a.x), dy = __fsub_rn(fy, a.y);
                 const float u = __fmaf_rn(a.z, dx, __fmul_rn(a.w, dy));
                 const float v = __fmaf_rn(b.x, dx, __fmul_rn(b.y, dy));
-                blend_fragment<PREMULT_C>(u, v, b.z, b.w, c.x, c.y, T, Cr, Cg, Cb, A);
+                blend_fragment<PREMULT_C, GENERAL>(u, v, b.z, b.w, c.x, c.y, T, Cr, Cg, Cb, A, bf);
             }
         }
     }

@@ -64,6 +64,7 @@ struct DrawArgs {
     KeySrc ks; int keybits = 32;   // v2: where the blend order comes from
     // the draw also executes the gs4d_keygen + gs4d_sort_pairs that were queued for it (first run only: a re-run finds the buffers sorted)
     bool fuse = false; gs4d_buf fuse_keys = 0, fuse_idx = 0; uint32_t fuse_span = 0xFFFFFFFFu;
+    int blend_src = GS4D_SRC_ALPHA, blend_dst = GS4D_ONE_MINUS_SRC_ALPHA;       // glBlendFunc state at the draw
 };
 
 struct Framebuffer {
@@ -127,6 +128,7 @@ struct gs4d_ctx {
     // behind the draw.  Any other call that could observe the buffers launches the stand-alone kernels first (flush_order).
     struct { bool keygen = false, sorted = false; int lane = 0; gs4d_buf data = 0, keys = 0, idx = 0; size_t n = 0; float t = 0; float cam[3] = { 0, 0, 0 };
              int key_mode = 0; uint32_t bias = 0, span = 0xFFFFFFFFu; float view[16] = { 0 }; } po;
+    int blend_src = GS4D_SRC_ALPHA, blend_dst = GS4D_ONE_MINUS_SRC_ALPHA;     // glBlendFunc state (Application.cpp:137-138, 150)
     bool defer_order = true;           // GS4D_FUSE_KEYGEN=0 switches the deferral off (test hook)
     uint64_t stat_fused = 0;
     int shrink_votes = 0, unslab_votes = 0;
@@ -280,7 +282,7 @@ int materialise_fb(gs4d_ctx* c) {
 }
 
 // Enqueue binning -> tile sort -> ranges -> composite for the projected records in L.proj.
-int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear) {
+int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, int blend_src, int blend_dst) {
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
@@ -301,7 +303,7 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, 
     {
         StageTimer t(c, GS4D_T_COMPOSITE);      // the per-tile ranges and the compositing kernel
         HIPCHK(c, launch_tile_ranges(L.s, L.bin, L.pair_keys, L.pair_cap, ntiles));
-        HIPCHK(c, launch_composite(L.s, L.proj, L.pair_vals, L.bin.ranges, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, F.mem));
+        HIPCHK(c, launch_composite(L.s, L.proj, L.pair_vals, L.bin.ranges, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, F.mem, blend_src, blend_dst));
     }
     return GS4D_OK;
 }
@@ -395,7 +397,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
-            else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, npre, a.u, c->W, c->H, po, tc));
+            else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, data->soa_n, npre, a.u, c->W, c->H, po, tc));
         }
         L.proj_n = npre;
         { int rc = fb_access(c, F); if (rc) return rc; }
@@ -421,7 +423,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
         }
         return rc;
     }
-    return enqueue_raster(c, L, F, order, order_copy, a.instances, npre, premult, a.fb_was_clear);
+    return enqueue_raster(c, L, F, order, order_copy, a.instances, npre, premult, a.fb_was_clear, a.blend_src, a.blend_dst);
 }
 
 // A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
@@ -756,7 +758,9 @@ int gs4d_set_clear_color(gs4d_ctx* c, const float rgba[4]) {
 }
 int gs4d_set_blend(gs4d_ctx* c, int src, int dst) {
     if (!c) return GS4D_E_INVALID;
-    if (src != GS4D_SRC_ALPHA || dst != GS4D_ONE_MINUS_SRC_ALPHA) return fail(c, GS4D_E_UNSUPPORTED, "set_blend: only (SRC_ALPHA, ONE_MINUS_SRC_ALPHA) is implemented");
+    auto known = [](int f) { return f == GS4D_ZERO || f == GS4D_ONE || (f >= GS4D_SRC_COLOR && f <= GS4D_ONE_MINUS_DST_COLOR) || (f >= GS4D_CONSTANT_COLOR && f <= GS4D_ONE_MINUS_CONSTANT_ALPHA); };
+    if (!known(src) || !known(dst)) return fail(c, GS4D_E_INVALID, "set_blend: not a glBlendFunc factor of the reference's menu (GL_INVALID_ENUM)");
+    c->blend_src = src; c->blend_dst = dst;              // like the GL's: state for the draws that follow
     return GS4D_OK;
 }
 int gs4d_clear(gs4d_ctx* c) {
@@ -895,7 +899,9 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     // bound index is this library's sort of its own depth keys for exactly these records — and the lists are short enough to be
     // ordered in LDS (validated on the device; a draw that turns out otherwise is re-run on the ordered path).
     a.v2 = false;
-    if (c->atomic_rank && c->path_pref != 1) {
+    a.blend_src = c->blend_src; a.blend_dst = c->blend_dst;
+    const bool over = a.blend_src == GS4D_SRC_ALPHA && a.blend_dst == GS4D_ONE_MINUS_SRC_ALPHA;       // any other function is applied in draw order: instance-ordered lists
+    if (c->atomic_rank && c->path_pref != 1 && over) {
         Buffer* data = getbuf(c, a.data);
         bool ok = false;
         size_t nkeys = 0;
@@ -991,7 +997,7 @@ int gs4d_draw_lines(gs4d_ctx* c, const float* verts, size_t nverts, int dims, in
     LineParams p;
     for (int i = 0; i < 16; ++i) p.vp[i] = viewproj ? viewproj[i] : (i % 5 == 0 ? 1.0f : 0.0f);
     for (int i = 0; i < 4; ++i) p.rgba[i] = std::min(std::max(rgba[i], 0.0f), 1.0f);      // the GL clamps fragment colours before blending into a fixed-point framebuffer
-    p.W = c->W; p.H = c->H;
+    p.W = c->W; p.H = c->H; p.blend_src = c->blend_src; p.blend_dst = c->blend_dst;
     HIPCHK(c, launch_lines(L.s, L.line_verts, nverts, dims, strip ? 1 : 0, p, width, F.linecnt, F.mem));
     ++c->ops;
     return GS4D_OK;

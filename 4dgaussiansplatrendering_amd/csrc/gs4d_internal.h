@@ -172,7 +172,7 @@ template <class F> __device__ __forceinline__ void for_each_tile(const TRect& r,
 hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* 6 planes of n float4 */, uint32_t* bbox /* [16], preset: min = ~0, max = 0 */);
 // Each preprocess launch also writes the compact pixel rectangle of every record.
 struct PreOut { float4* proj; uint2* rects; };
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n /* records in the buffer: the plane stride */, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 
@@ -194,14 +194,14 @@ hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pai
 
 // ---- composite.hip ----
 hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
-                            int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb);
+                            int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb, int blend_src, int blend_dst);
 hipError_t launch_fill(hipStream_t st, float4* fb, size_t npix, const float clear[4]);
 hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, size_t npix, uint32_t* out);
 // the pixel rows of the tile rows ty % world == rank, top of the band = the context's first tile row; band_rows pixel rows in all
 hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, int W, int H, int rank, int world, int band_rows, uint32_t* out);
 
 // ---- lines.hip ----
-struct LineParams { float vp[16]; float rgba[4]; int W, H; };
+struct LineParams { float vp[16]; float rgba[4]; int W, H; int blend_src, blend_dst; };
 // verts_dev: nverts positions of `dims` floats on the device; cnt: W*H fragment counters, all-zero between calls
 hipError_t launch_lines(hipStream_t st, const float* verts_dev, size_t nverts, int dims, int strip, const LineParams& p, float width, uint32_t* cnt, float4* fb);
 

@@ -16,6 +16,7 @@
 // counts fragments per pixel (atomics on a per-image counter plane that is all-zero between calls), a second one lets the first
 // fragment that arrives at a pixel take the count, apply the blend that many times and clear the counter.
 #include "gs4d_internal.h"
+#include "composite_common.h"
 #include <algorithm>
 
 namespace gs4d {
@@ -103,9 +104,14 @@ __global__ __launch_bounds__(256) void k_lines_blend(const float* __restrict__ v
     float4 d = fb[o];
     const float a = p.rgba[3], om = __fsub_rn(1.0f, a);
     const float sr = __fmul_rn(p.rgba[0], a), sg = __fmul_rn(p.rgba[1], a), sb = __fmul_rn(p.rgba[2], a), sa = __fmul_rn(a, a);
-    for (uint32_t q = 0; q < k; ++q) {
-        d.x = __fadd_rn(sr, __fmul_rn(d.x, om)); d.y = __fadd_rn(sg, __fmul_rn(d.y, om));
-        d.z = __fadd_rn(sb, __fmul_rn(d.z, om)); d.w = __fadd_rn(sa, __fmul_rn(d.w, om));
+    if (p.blend_src == GS4D_SRC_ALPHA && p.blend_dst == GS4D_ONE_MINUS_SRC_ALPHA) {
+        for (uint32_t q = 0; q < k; ++q) {
+            d.x = __fadd_rn(sr, __fmul_rn(d.x, om)); d.y = __fadd_rn(sg, __fmul_rn(d.y, om));
+            d.z = __fadd_rn(sb, __fmul_rn(d.z, om)); d.w = __fadd_rn(sa, __fmul_rn(d.w, om));
+        }
+    } else {
+        const BlendFn bf{ p.blend_src, p.blend_dst };       // any other glBlendFunc: the same fragment, k times over
+        for (uint32_t q = 0; q < k; ++q) blend_general(bf, p.rgba[0], p.rgba[1], p.rgba[2], a, d.x, d.y, d.z, d.w);
     }
     fb[o] = d;
 }

@@ -240,14 +240,15 @@ __device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float
 }
 
 // One record each: returns its pixel rectangle, and through `key` its blend-order key (unordered path).
-struct Src4D { const float4* soa; };
+struct Src4D { const float4* soa; uint32_t stride; };      // six planes of `stride` float4 (the buffer's record count, not the draw's)
 struct Src3D { const float* verts; };
 struct Src2D { const float* recs; };
 
 __device__ __forceinline__ uint2 project_record(const Src4D& src, uint32_t n, uint32_t i, const PU& u, const PreOut& out, const KeySrc& ks, uint32_t& key) {
     const float4* __restrict__ soa = src.soa;
-    const float4 pos = soa[i], col = soa[(size_t)n + i];
-    const float4 s0 = soa[(size_t)2 * n + i], s1 = soa[(size_t)3 * n + i], s2 = soa[(size_t)4 * n + i], s3 = soa[(size_t)5 * n + i];
+    const size_t ps = src.stride;
+    const float4 pos = soa[i], col = soa[ps + i];
+    const float4 s0 = soa[2 * ps + i], s1 = soa[3 * ps + i], s2 = soa[4 * ps + i], s3 = soa[5 * ps + i];
     float s44 = s3.w;
     float dt = u.time - pos.w;
     float ot = maxf_glsl(expf(-0.5f * dt * (1.0f / s44) * dt), u.min_opacity);     // :48-51, 83
@@ -372,7 +373,7 @@ static hipError_t launch_pre(hipStream_t st, SRC src, size_t n, const Uniforms& 
     else k_preprocess<SRC><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src4D{ soa }, n, un, W, H, out, tc); }
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src4D{ soa, (uint32_t)soa_n }, n, un, W, H, out, tc); }
 hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src3D{ verts72 }, n, un, W, H, out, tc); }
 hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src2D{ rec48 }, n, un, W, H, out, tc); }
 

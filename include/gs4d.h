@@ -60,7 +60,10 @@ enum { GS4D_U_VIEW = 0, GS4D_U_PROJ = 1 };         /* uView, uProj       (Scenes
 enum { GS4D_KEY_REF_INV_EUCLID = 0,  /* 1/|mean'(t) - cam|, the reference's key (Scenes.h:28-36, 314-319) */
        GS4D_KEY_VIEW_Z = 1 };        /* extra: key = 1/(-z_view) of the time-conditioned mean              */
 
-enum { GS4D_SRC_ALPHA = 0x0302, GS4D_ONE_MINUS_SRC_ALPHA = 0x0303 };  /* GL enum values, Application.cpp:137-138, 150 */
+/* glBlendFunc factors: GL enum values (Application.cpp:137-138, 150); the set is the one the reference's blend menu offers (DebugMenus.h:41-59) */
+enum { GS4D_ZERO = 0, GS4D_ONE = 1, GS4D_SRC_COLOR = 0x0300, GS4D_ONE_MINUS_SRC_COLOR = 0x0301, GS4D_SRC_ALPHA = 0x0302, GS4D_ONE_MINUS_SRC_ALPHA = 0x0303,
+       GS4D_DST_ALPHA = 0x0304, GS4D_ONE_MINUS_DST_ALPHA = 0x0305, GS4D_DST_COLOR = 0x0306, GS4D_ONE_MINUS_DST_COLOR = 0x0307,
+       GS4D_CONSTANT_COLOR = 0x8001, GS4D_ONE_MINUS_CONSTANT_COLOR = 0x8002, GS4D_CONSTANT_ALPHA = 0x8003, GS4D_ONE_MINUS_CONSTANT_ALPHA = 0x8004 };
 
 /* Per-stage device timings of the most recent calls, measured with HIP events on the context's stream. */
 enum { GS4D_T_KEYGEN = 0, GS4D_T_SORT = 1, GS4D_T_PREPROCESS = 2, GS4D_T_BINNING = 3, GS4D_T_PAIRSORT = 4, GS4D_T_COMPOSITE = 5, GS4D_T_COUNT = 6 };
@@ -93,7 +96,11 @@ GS4D_API int gs4d_set_mode(gs4d_ctx* ctx, int mode);
 GS4D_API int gs4d_set_uniform_1f(gs4d_ctx* ctx, int id, float v);
 GS4D_API int gs4d_set_uniform_mat4(gs4d_ctx* ctx, int id, const float m[16]);
 GS4D_API int gs4d_set_clear_color(gs4d_ctx* ctx, const float rgba[4]);
-GS4D_API int gs4d_set_blend(gs4d_ctx* ctx, int src_factor, int dst_factor);      /* only (SRC_ALPHA, ONE_MINUS_SRC_ALPHA), the reference's default */
+/* glBlendFunc(sfactor, dfactor) (Application.cpp:150): equation FUNC_ADD on all four channels, result clamped to [0, 1].  Default
+ * (SRC_ALPHA, ONE_MINUS_SRC_ALPHA).  The blend colour is (0, 0, 0, 0) as in the reference (no glBlendColor): CONSTANT_* act as ZERO,
+ * ONE_MINUS_CONSTANT_* as ONE.  Any other value: GS4D_E_INVALID (GL_INVALID_ENUM).  Draws with a function other than the default take
+ * the instance-ordered tile lists and blend them in draw order. */
+GS4D_API int gs4d_set_blend(gs4d_ctx* ctx, int src_factor, int dst_factor);
 GS4D_API int gs4d_clear(gs4d_ctx* ctx);
 
 /* ---- ordering ---- */

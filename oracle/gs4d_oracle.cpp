@@ -561,9 +561,45 @@ static inline bool gs4do_fragment(const gs4do_proj& p, int frag_mode, float u, f
     return true;
 }
 
+// glBlendFunc(sfactor, dfactor) with the default equation FUNC_ADD (OpenGL 4.4, 17.3.8, tables 17.1/17.2), the factors the reference's
+// menu offers (DebugMenus.h:41-59), applied to all four channels (glBlendFunc sets the RGB and the alpha factors alike).  Fixed-point
+// framebuffer: the source is clamped before (done by the callers), the result after.  The blend colour is never set by the reference
+// (no glBlendColor call): it stays (0, 0, 0, 0), so CONSTANT_* = 0 and ONE_MINUS_CONSTANT_* = 1.
+static inline float gs4do_blend_factor(int f, int ch, const float src[4], const float dst[4]) {
+    switch (f) {
+    case 0:      return 0.0f;                 // GL_ZERO
+    case 1:      return 1.0f;                 // GL_ONE
+    case 0x0300: return src[ch];              // GL_SRC_COLOR
+    case 0x0301: return 1.0f - src[ch];       // GL_ONE_MINUS_SRC_COLOR
+    case 0x0302: return src[3];               // GL_SRC_ALPHA
+    case 0x0303: return 1.0f - src[3];        // GL_ONE_MINUS_SRC_ALPHA
+    case 0x0304: return dst[3];               // GL_DST_ALPHA
+    case 0x0305: return 1.0f - dst[3];        // GL_ONE_MINUS_DST_ALPHA
+    case 0x0306: return dst[ch];              // GL_DST_COLOR
+    case 0x0307: return 1.0f - dst[ch];       // GL_ONE_MINUS_DST_COLOR
+    case 0x8001: case 0x8003: return 0.0f;    // GL_CONSTANT_COLOR / GL_CONSTANT_ALPHA
+    case 0x8002: case 0x8004: return 1.0f;    // GL_ONE_MINUS_CONSTANT_*
+    default:     return 0.0f;
+    }
+}
+static inline void gs4do_blend(int sf, int df, const float src[4], float* d) {
+    float out[4];
+    for (int q = 0; q < 4; ++q) {
+        const float S = gs4do_blend_factor(sf, q, src, d), D = gs4do_blend_factor(df, q, src, d);
+        out[q] = fminf(fmaxf(src[q] * S + d[q] * D, 0.0f), 1.0f);
+    }
+    d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3];
+}
+
 // Ordered "over" blend into an RGBA32F image (row 0 = bottom), instance order = order[k] (or k if order == NULL).
 // Application.cpp:150-154 : dst = src*src.a + dst*(1-src.a) on all four channels, depth test off.
+GS4DO_API void gs4do_composite_blend(const gs4do_proj* proj, const uint32_t* order, size_t ninst, int frag_mode, int W, int H, float* rgba, int nthreads, int sf, int df);
 GS4DO_API void gs4do_composite(const gs4do_proj* proj, const uint32_t* order, size_t ninst, int frag_mode, int W, int H, float* rgba, int nthreads) {
+    gs4do_composite_blend(proj, order, ninst, frag_mode, W, H, rgba, nthreads, 0x0302, 0x0303);
+}
+// The same with any blend function of the menu (Application.cpp:150 glBlendFunc(blendOpt.selected0, blendOpt.selected1)).
+GS4DO_API void gs4do_composite_blend(const gs4do_proj* proj, const uint32_t* order, size_t ninst, int frag_mode, int W, int H, float* rgba, int nthreads, int sf, int df) {
+    const bool over = sf == 0x0302 && df == 0x0303;
     if (nthreads < 1) nthreads = 1;
     auto band = [&](int j0, int j1) {
         for (size_t k = 0; k < ninst; ++k) {
@@ -582,6 +618,7 @@ GS4DO_API void gs4do_composite(const gs4do_proj* proj, const uint32_t* order, si
                     // the reference's framebuffer is fixed-point (RGBA8): fragment colour and alpha are clamped to [0, 1] before the blend (OpenGL 4.4, 17.3.8)
                     for (int q = 0; q < 4; ++q) src[q] = fminf(fmaxf(src[q], 0.0f), 1.0f);
                     float* d = rgba + 4 * ((size_t)j * W + i);
+                    if (!over) { gs4do_blend(sf, df, src, d); continue; }
                     float a = src[3], ia = 1.0f - a;
                     d[0] = src[0] * a + d[0] * ia; d[1] = src[1] * a + d[1] * ia; d[2] = src[2] * a + d[2] * ia; d[3] = src[3] * a + d[3] * ia;
                 }
@@ -605,7 +642,12 @@ static bool clip_t(float num, float den, float& t0, float& t1) {
     else { if (t < t0) return false; if (t < t1) t1 = t; }
     return true;
 }
+GS4DO_API void gs4do_draw_lines_blend(float* rgba, int W, int H, const float* verts, size_t nverts, int dims, int strip, const float* M, const float color[4], float width, int sf, int df);
 GS4DO_API void gs4do_draw_lines(float* rgba, int W, int H, const float* verts, size_t nverts, int dims, int strip, const float* M, const float color[4], float width) {
+    gs4do_draw_lines_blend(rgba, W, H, verts, nverts, dims, strip, M, color, width, 0x0302, 0x0303);
+}
+GS4DO_API void gs4do_draw_lines_blend(float* rgba, int W, int H, const float* verts, size_t nverts, int dims, int strip, const float* M, const float color[4], float width, int sf, int df) {
+    const bool over = sf == 0x0302 && df == 0x0303;
     const size_t nseg = strip ? (nverts >= 2 ? nverts - 1 : 0) : nverts / 2;
     int wpx = (int)floorf(width + 0.5f); if (!(wpx >= 1)) wpx = 1; if (wpx > 64) wpx = 64;
     float col[4]; for (int q = 0; q < 4; ++q) col[q] = fminf(fmaxf(color[q], 0.0f), 1.0f);      // clamped like every fragment colour
@@ -651,6 +693,7 @@ GS4DO_API void gs4do_draw_lines(float* rgba, int W, int H, const float* verts, s
                 const float x = xmajor ? i : j, y = xmajor ? j : i;
                 if (!(x >= 0.0f && y >= 0.0f && x < (float)W && y < (float)H)) continue;
                 float* d = rgba + 4 * ((size_t)(int)y * W + (int)x);
+                if (!over) { gs4do_blend(sf, df, col, d); continue; }
                 d[0] = sr + d[0] * om; d[1] = sg + d[1] * om; d[2] = sb + d[2] * om; d[3] = sa + d[3] * om;
             }
         }

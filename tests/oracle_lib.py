@@ -147,7 +147,10 @@ def preprocess(mode, data, view, proj, W, H, t=0.0, min_opacity=0.0):
     return out
 
 
-def composite(proj_arr, order, frag_mode, W, H, rgba, nthreads=8):
+BLEND_OVER = (0x0302, 0x0303)          # glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA), Application.cpp:137-138
+
+
+def composite(proj_arr, order, frag_mode, W, H, rgba, nthreads=8, blend=BLEND_OVER):
     assert rgba.dtype == np.float32 and rgba.size == W * H * 4 and rgba.flags.c_contiguous
     if order is not None:
         order = np.ascontiguousarray(order, dtype=np.uint32)
@@ -155,17 +158,19 @@ def composite(proj_arr, order, frag_mode, W, H, rgba, nthreads=8):
     else:
         n = proj_arr.size
     fm = MODE_4D if frag_mode == MODE_4D_DIRECT else frag_mode
-    lib().gs4do_composite(_p(proj_arr), _p(order) if order is not None else None, C.c_size_t(n), C.c_int(fm), C.c_int(W), C.c_int(H), _p(rgba), C.c_int(nthreads))
+    lib().gs4do_composite_blend(_p(proj_arr), _p(order) if order is not None else None, C.c_size_t(n), C.c_int(fm), C.c_int(W), C.c_int(H), _p(rgba), C.c_int(nthreads),
+                                C.c_int(blend[0]), C.c_int(blend[1]))
     return rgba
 
 
-def draw_lines(rgba, verts, color, width=1.0, viewproj=None, strip=False):
+def draw_lines(rgba, verts, color, width=1.0, viewproj=None, strip=False, blend=BLEND_OVER):
     """Overlay lines blended into `rgba` (H, W, 4) in place; verts (n, 3) with viewproj or (n, 2) NDC."""
     H, W = rgba.shape[:2]
     v = _f32(verts)
     dims = v.shape[-1]
     vp = _f32(viewproj) if viewproj is not None else np.eye(4, dtype=np.float32).reshape(-1)
-    lib().gs4do_draw_lines(_p(rgba), C.c_int(W), C.c_int(H), _p(v), C.c_size_t(v.size // dims), C.c_int(dims), C.c_int(1 if strip else 0), _p(vp), _p(_f32(color)), C.c_float(width))
+    lib().gs4do_draw_lines_blend(_p(rgba), C.c_int(W), C.c_int(H), _p(v), C.c_size_t(v.size // dims), C.c_int(dims), C.c_int(1 if strip else 0), _p(vp), _p(_f32(color)), C.c_float(width),
+                                 C.c_int(blend[0]), C.c_int(blend[1]))
     return rgba
 
 

@@ -460,3 +460,86 @@ def test_queued_keygen_is_launched_when_something_else_follows(gs4d, oracle, mon
     assert linf(ctx.read_pixels(), oracle.composite(eproj, rev, oracle.MODE_4D, W, H, oracle.clear_image(W, H))) <= TOL
     assert ctx.stats()["fused_keygen_draws"] == 0
     ctx.close()
+
+
+# ---- glBlendFunc other than the default (Application.cpp:150 takes both factors from the blend menu, DebugMenus.h:41-59) ----
+BLENDS = [("ONE", "ONE"), ("SRC_ALPHA", "ONE"), ("ONE", "ZERO"), ("ZERO", "ONE"), ("DST_COLOR", "ZERO"), ("ONE_MINUS_DST_ALPHA", "DST_ALPHA"),
+          ("SRC_COLOR", "ONE_MINUS_SRC_COLOR"), ("ONE_MINUS_DST_COLOR", "ONE_MINUS_SRC_ALPHA"), ("ONE_MINUS_CONSTANT_ALPHA", "CONSTANT_COLOR"),
+          ("SRC_ALPHA", "ONE_MINUS_SRC_ALPHA")]
+
+
+@pytest.mark.parametrize("sf,df", BLENDS)
+def test_blend_functions_of_the_menu(gs4d, oracle, monkeypatch, sf, df):
+    """Lines, then 4D splats in sorted order, then 3D-Full quads (premultiplied colour), all with the selected function."""
+    n, W, H = 6000, 480, 270
+    blend = (getattr(gs4d, sf), getattr(gs4d, df))
+    pos4, q, sc, life, fade, vel, rgba = scenes.cube_params_4d(n, seed=71)
+    rec = gs4d.build_records_4d(pos4, q, sc * 6.0, life, fade, vel, rgba)
+    cam, t = scenes.CAM_CUBE, 2.0
+    view, proj = cam_mats(gs4d, cam, W, H)
+    grid = np.array([[np.cos(a), np.sin(a)] for k in range(9) for a in (k * 0.35, k * 0.35 + np.pi)], np.float32) * 0.9     # 2D (NDC) segments crossing in one pixel
+    col = np.array([0.9, 0.4, 0.2, 0.6], np.float32)
+    ctx = _ctx(gs4d, W, H, monkeypatch)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_blend(*blend)
+    ctx.clear()
+    ctx.draw_lines(grid, col, width=2.0)
+    db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+    ctx.keygen(db, t, cam[0], kb, ib, n)
+    ctx.sort_pairs(kb, ib, n)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.bind(1, ib)
+    ctx.bind(2, db)
+    ctx.draw_instanced(n)
+    img1 = ctx.read_pixels()
+    st = ctx.stats()
+    # a second draw on top of the first, in record order (4D direct): the blend starts from what the first left
+    ctx.set_mode(gs4d.MODE_4D_DIRECT)
+    ctx.bind(1, db)
+    ctx.draw_instanced(n // 2)
+    img2 = ctx.read_pixels()
+    ctx.close()
+    over = blend == oracle.BLEND_OVER
+    assert (st["unordered_draws"] > 0) == over                    # any other function is blended in draw order from instance-ordered lists
+    _, skeys, eperm, eproj = _expected_frame(oracle, rec, t, cam, view, proj, W, H, False)
+    e = oracle.clear_image(W, H)
+    oracle.draw_lines(e, grid, col, width=2.0, blend=blend)
+    oracle.composite(eproj, eperm, oracle.MODE_4D, W, H, e, blend=blend)
+    assert linf(img1, e) <= TOL
+    oracle.composite(eproj, np.arange(n // 2, dtype=np.uint32), oracle.MODE_4D, W, H, e, blend=blend)
+    assert linf(img2, e) <= TOL
+    if (sf, df) in (("ZERO", "ONE"), ("ONE_MINUS_DST_ALPHA", "DST_ALPHA")):
+        assert linf(img2, oracle.clear_image(W, H)) == 0.0        # nothing drawn changes anything (the second pair: destination alpha is 1 from the clear on)
+    else:
+        assert linf(img1, oracle.clear_image(W, H)) > 0.05
+
+
+def test_blend_function_with_premultiplied_quads(gs4d, oracle, monkeypatch):
+    """3D-Full fragments carry colour * c (Splat3DFragShaderFull.GLSL:22): the premultiplied-alpha "over" (ONE, ONE_MINUS_SRC_ALPHA)."""
+    W, H, n = 400, 400, 64
+    cam = ((0.0, 0.0, 10.0), (0.0, 0.0, -1.0))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    pos, q, scale, rgba = scenes.cube_params(n, seed=72)
+    verts = np.zeros((n, 4, 18), np.float32)                      # {corner2, pos3, col4, sig9} x 4 vertices  (Geometry.h:37-42, Splat.h:433-447)
+    corners = np.array([[0.5, 0.5], [0.5, -0.5], [-0.5, -0.5], [-0.5, 0.5]], np.float32)
+    for i in range(n):
+        verts[i, :, 0:2] = corners
+        verts[i, :, 2:5] = pos[i] * 0.02
+        verts[i, :, 5:9] = rgba[i]
+        verts[i, :, 9:18] = gs4d.splat3d_cov(q[i], scale[i] * 0.6)
+    blend = (gs4d.ONE, gs4d.ONE_MINUS_SRC_ALPHA)
+    ctx = _ctx(gs4d, W, H, monkeypatch)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_blend(*blend)
+    ctx.clear()
+    ctx.set_uniforms(view=view, proj=proj)
+    ctx.set_mode(gs4d.MODE_3D_FULL)
+    vb = ctx.buffer(verts)
+    ctx.draw_quads(vb, n)
+    img = ctx.read_pixels()
+    ctx.close()
+    eproj = oracle.preprocess(oracle.MODE_3D, verts, view, proj, W, H)
+    e = oracle.composite(eproj, None, oracle.MODE_3D, W, H, oracle.clear_image(W, H), blend=blend)
+    assert linf(img, e) <= TOL
+    assert linf(e, oracle.composite(eproj, None, oracle.MODE_3D, W, H, oracle.clear_image(W, H))) > 0.01       # and it is not the default function's image

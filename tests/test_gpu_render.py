@@ -395,7 +395,8 @@ def test_mode_3d_full_and_2d(gs4d, oracle):
 def test_errors_and_state(gs4d):
     ctx = gs4d.Context(64, 64)
     with pytest.raises(gs4d.Gs4dError):
-        ctx.set_blend(gs4d.SRC_ALPHA, gs4d.SRC_ALPHA)            # only the reference's default blend is implemented
+        ctx.set_blend(gs4d.SRC_ALPHA, 0x0308)                    # GL_SRC_ALPHA_SATURATE: not a factor of the reference's menu -> GL_INVALID_ENUM
+    ctx.set_blend(gs4d.SRC_ALPHA, gs4d.SRC_ALPHA)                # any pair of the menu's factors is accepted (test_gpu_paths covers the blending)
     ctx.set_blend(gs4d.SRC_ALPHA, gs4d.ONE_MINUS_SRC_ALPHA)
     with pytest.raises(gs4d.Gs4dError):
         ctx.draw_instanced(10)                                    # nothing bound

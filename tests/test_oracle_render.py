@@ -169,3 +169,37 @@ def test_teapot_agrees_with_the_reference_screenshot():
     blown[:, 8:] *= 64.0
     iou2, _ = compare(blown)
     assert iou2 < 0.5
+
+
+def test_blend_functions_against_a_direct_statement(oracle):
+    """gs4do_composite_blend against OpenGL 4.4 tables 17.1/17.2 written out in numpy for one pixel stack (FUNC_ADD, clamped, blend colour 0)."""
+    rng = np.random.default_rng(5)
+    W = H = 8
+    n = 12
+    proj = np.zeros(n, oracle.PROJ_DTYPE)
+    # n quads that all cover the whole 8x8 image with a flat Gaussian (c ~ 1 at the centre pixel row is not needed: take c from the oracle's own fragment)
+    proj["valid"] = 1
+    proj["cx"], proj["cy"] = 4.0, 4.0
+    proj["a0x"], proj["a1y"] = 1.0 / 64.0, 1.0 / 64.0
+    proj["hx"], proj["hy"] = 32.0, 32.0
+    for f in ("e0x", "e1y"):
+        proj[f] = 1.0
+    proj["s0"], proj["s1"] = 1.0, 1.0
+    proj["q00"], proj["q11"] = 1.0, 1.0
+    proj["alpha"] = rng.uniform(0.2, 0.9, n).astype(np.float32)
+    proj["r"], proj["g"], proj["b"] = (rng.uniform(0, 1, n).astype(np.float32) for _ in range(3))
+    over = oracle.composite(proj, None, oracle.MODE_4D, W, H, oracle.clear_image(W, H))
+    fac = {0: lambda s, d, c: 0.0, 1: lambda s, d, c: 1.0, 0x0300: lambda s, d, c: s[c], 0x0301: lambda s, d, c: 1 - s[c], 0x0302: lambda s, d, c: s[3],
+           0x0303: lambda s, d, c: 1 - s[3], 0x0304: lambda s, d, c: d[3], 0x0305: lambda s, d, c: 1 - d[3], 0x0306: lambda s, d, c: d[c], 0x0307: lambda s, d, c: 1 - d[c],
+           0x8001: lambda s, d, c: 0.0, 0x8002: lambda s, d, c: 1.0, 0x8003: lambda s, d, c: 0.0, 0x8004: lambda s, d, c: 1.0}
+    # the fragment values of pixel (4, 4): recovered from single-quad renders with (ONE, ZERO) = "the fragment replaces the pixel"
+    frags = [oracle.composite(proj[k:k + 1], None, oracle.MODE_4D, W, H, oracle.clear_image(W, H), blend=(1, 0))[4, 4].astype(np.float64) for k in range(n)]
+    for sf in fac:
+        for df in fac:
+            img = oracle.composite(proj, None, oracle.MODE_4D, W, H, oracle.clear_image(W, H), blend=(sf, df))
+            d = oracle.CLEAR.astype(np.float64).copy()
+            for s_ in frags:
+                d = np.clip(np.array([s_[c] * fac[sf](s_, d, c) + d[c] * fac[df](s_, d, c) for c in range(4)]), 0.0, 1.0)
+            assert np.abs(img[4, 4] - d).max() <= 2e-6, (hex(sf), hex(df))
+            if (sf, df) == (0x0302, 0x0303):
+                assert np.array_equal(img, over)
