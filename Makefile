@@ -3,6 +3,7 @@ PKG   := 4dgaussiansplatrendering_amd
 CSRC  := $(PKG)/csrc
 HOST  := $(PKG)/host
 HIPCC ?= hipcc
+ROCM ?= /opt/rocm
 ARCH  ?= gfx950
 LIB   := $(PKG)/libgs4d.so
 
@@ -16,10 +17,15 @@ STRICT   := -ffp-contract=off
 
 OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(CSRC)/tilelist.o $(CSRC)/composite2.o $(CSRC)/lines.o $(HOST)/gs4d_host.o
 
-.PHONY: all lib oracle ref refscene clean demo
-all: lib oracle demo
+.PHONY: all lib oracle ref refscene clean demo sweep
+all: lib oracle demo sweep
 DEMO := $(HOST)/scene_replay
+SWEEP := $(HOST)/gs4d_sweep
 demo: $(DEMO)
+# the multi-GPU sweep (BASELINE.json configs[3]) driven from C++: the C ABI + HIP + RCCL, one process per GPU
+sweep: $(SWEEP)
+$(SWEEP): $(HOST)/gs4d_sweep.cpp include/gs4d.h $(LIB)
+	g++ -O2 -std=c++17 -Wall -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include $(HOST)/gs4d_sweep.cpp -o $@ -L$(PKG) -lgs4d -L$(ROCM)/lib -lrccl -lamdhip64 -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib
 $(DEMO): $(HOST)/scene_replay.cpp $(HOST)/gs4d_compat.h include/gs4d.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -o $@ $(HOST)/scene_replay.cpp -L$(PKG) -lgs4d -Wl,-rpath,'$$ORIGIN/..'
 lib: $(LIB)
@@ -46,5 +52,5 @@ refscene: lib
 	$(MAKE) -C oracle refscene
 
 clean:
-	rm -f $(OBJS) $(LIB) $(DEMO)
+	rm -f $(OBJS) $(LIB) $(DEMO) $(SWEEP)
 	$(MAKE) -C oracle clean
