@@ -45,6 +45,9 @@ struct Buffer {
     unsigned tail_mask = 0;        // lanes whose other kernels (key generation) have read it since that write (their tail event does)
     uint64_t touch = 0;            // context op counter at the last device-side use (host writes compare it with the last full sync)
     bool alive = false;
+    // The caller announced (gs4d_buffer_invalidate) that work on ITS stream rewrites the buffer: every lane that uses it afterwards first
+    // waits for an event recorded on that stream at the first such use (the caller has queued the writes by then: that is the contract).
+    hipEvent_t ev_fill = nullptr; unsigned fill_mask = 0; bool fill_recorded = false;
     // Provenance of a sort index: set when gs4d_sort_pairs has sorted exactly the keys and the identity index gs4d_keygen wrote for
     // `prov_data` — the contents are then "records of prov_data in ascending (depth key, record index)" for as long as `version`
     // still equals prov_ver, and a draw that binds it can take its blend order from the keys instead of reading it (tilelist.hip).
@@ -199,7 +202,18 @@ int after_user_stream(gs4d_ctx* c) {
 // (or, for a write, still read it).  Device-side waits only.  A lane other than the current one has been left since it last touched
 // B, so its tail event (recorded on leaving) covers that use; a draw's reads are already covered by its binning-done event.
 int resolve_lane(gs4d_ctx* c, int li);
+int after_user_fill(gs4d_ctx* c, Buffer& B) {
+    const unsigned me = 1u << c->cur;
+    if (!(B.fill_mask & me)) return GS4D_OK;
+    B.fill_mask &= ~me;
+    if (!c->user) { B.fill_mask = 0; return GS4D_OK; }
+    if (!B.ev_fill) HIPCHK(c, hipEventCreateWithFlags(&B.ev_fill, hipEventDisableTiming));
+    if (!B.fill_recorded) { HIPCHK(c, hipEventRecord(B.ev_fill, c->user)); B.fill_recorded = true; }
+    HIPCHK(c, hipStreamWaitEvent(lane(c).s, B.ev_fill, 0));
+    return GS4D_OK;
+}
 int lane_access(gs4d_ctx* c, Buffer& B, bool write) {
+    { int rc = after_user_fill(c, B); if (rc) return rc; }
     if (write) {
         // An unordered draw never read its sort index — but if its validation fails it is re-run on the ordered path, which does.
         // Validate such draws before the index they were given is overwritten (in steady state their event completed long ago).
@@ -243,6 +257,7 @@ int ensure_soa(gs4d_ctx* c, Buffer& b) {
     const size_t n = b.bytes / 96;
     if (b.soa && b.soa_n == n && b.soa_version == b.version) return GS4D_OK;
     if (b.touch > c->synced) { int rc = sync_all(c); if (rc) return rc; }      // a running draw may still project from the old shadow
+    { int rc = after_user_fill(c, b); if (rc) return rc; }                     // the repack reads what the caller's stream is writing
     Lane& L = lane(c);
     if (!b.soa || b.soa_n != n) {
         if (b.soa) { (void)hipFree(b.soa); b.soa = nullptr; }
@@ -595,7 +610,7 @@ void gs4d_destroy(gs4d_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (int i = 0; i < MAX_LANES; ++i) if (c->lanes[i].s) (void)hipStreamSynchronize(c->lanes[i].s);
-    for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); if (b.bbox_dev) (void)hipFree(b.bbox_dev); }
+    for (auto& b : c->bufs) { if (b.d) (void)hipFree(b.d); if (b.soa) (void)hipFree(b.soa); if (b.bbox_dev) (void)hipFree(b.bbox_dev); if (b.ev_fill) (void)hipEventDestroy(b.ev_fill); }
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
         if (c->fbs[i].mem) (void)hipFree(c->fbs[i].mem);
@@ -687,6 +702,7 @@ int gs4d_buffer_destroy(gs4d_ctx* c, gs4d_buf b) {
     if (B->d) (void)hipFree(B->d);
     if (B->soa) (void)hipFree(B->soa);
     if (B->bbox_dev) (void)hipFree(B->bbox_dev);
+    if (B->ev_fill) (void)hipEventDestroy(B->ev_fill);
     *B = Buffer();
     for (auto& s : c->slots) if (s == b) s = 0;     // a deleted buffer is unbound
     for (int i = 0; i < c->nlanes; ++i) if (c->lanes[i].kg_buf == b) c->lanes[i].kg_buf = 0;
@@ -723,6 +739,7 @@ int gs4d_buffer_invalidate(gs4d_ctx* c, gs4d_buf b) {
     }
     B->version++;                                             // SoA shadow, key bounds, histogram hand-off and sort-index provenance all compare against it
     B->prov_valid = false;
+    if (c->user) { B->fill_mask = (1u << c->nlanes) - 1u; B->fill_recorded = false; }      // whoever uses it next waits for the caller's stream
     return GS4D_OK;
 }
 
@@ -791,14 +808,14 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     if (c->po.keygen && !c->po.sorted && keys == c->po.keys && vals == c->po.idx && n == c->po.n && c->cur == c->po.lane && !lane(c).drawn) {
         // the sort of a queued key generation's own output: queued with it; what the index will have been sorted by is known now
         Lane& Lq = lane(c);
-        { int rc = after_user_stream(c); if (rc) return rc; rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *V, true); if (rc) return rc; }
+        { int rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *V, true); if (rc) return rc; }
         c->po.sorted = true;
         c->stat_depth_passes = (uint64_t)std::max(2, (Lq.depth_sort.hist_bits + 7) / 8);
         K->version++; V->version++;
         V->prov_valid = true; V->prov_data = Lq.kg_data; V->prov_data_ver = Lq.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = Lq.kg_bits; V->prov_ks = Lq.kg_ks;
         return GS4D_OK;
     }
-    { int rc = flush_order(c); if (rc) return rc; rc = next_frame_if_drawn(c); if (rc) return rc; rc = after_user_stream(c); if (rc) return rc; }
+    { int rc = flush_order(c); if (rc) return rc; rc = next_frame_if_drawn(c); if (rc) return rc; }
     { int rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *V, true); if (rc) return rc; }
     Lane& L = lane(c);
     // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
@@ -823,7 +840,7 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     if (key_mode != GS4D_KEY_REF_INV_EUCLID && key_mode != GS4D_KEY_VIEW_Z) return fail(c, GS4D_E_INVALID, "keygen: unknown key mode");
     if (n >= 0xFFFFFFFFull || D->bytes < n * 96 || K->bytes < n * 4 || I->bytes < n * 4) return fail(c, GS4D_E_INVALID, "keygen: buffers smaller than n elements");
     if (n == 0) return GS4D_OK;
-    { int rc = flush_order(c); if (rc) return rc; rc = next_frame_if_drawn(c); if (rc) return rc; rc = after_user_stream(c); if (rc) return rc; }
+    { int rc = flush_order(c); if (rc) return rc; rc = next_frame_if_drawn(c); if (rc) return rc; }
     int rc = ensure_soa(c, *D); if (rc) return rc;
     { rc = lane_access(c, *D, false); if (rc) return rc; D->tail_mask |= 1u << c->cur; rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *I, true); if (rc) return rc; }
     Lane& L = lane(c);
@@ -891,7 +908,6 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     // (not the other lanes' draws: their frames are still in flight and nothing here depends on them)
     int rc = resolve_lane(c, c->cur); if (rc) return rc;
     rc = resolve_image(c, c->cur_fb); if (rc) return rc;
-    rc = after_user_stream(c); if (rc) return rc;
     Lane& L = lane(c);
     a.lane = c->cur; a.fb = c->cur_fb;
     a.fb_was_clear = c->fbs[c->cur_fb].is_clear;
@@ -976,7 +992,6 @@ int gs4d_draw_lines(gs4d_ctx* c, const float* verts, size_t nverts, int dims, in
     if (nverts > 0x7FFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw_lines: too many vertices");
     // lines blend into the image in call order: a splat draw into it that still awaits validation (and may be re-run) goes first
     int rc = resolve_image(c, c->cur_fb); if (rc) return rc;
-    rc = after_user_stream(c); if (rc) return rc;
     rc = materialise_fb(c); if (rc) return rc;
     Framebuffer& F = c->fbs[c->cur_fb];
     rc = fb_access(c, F); if (rc) return rc;

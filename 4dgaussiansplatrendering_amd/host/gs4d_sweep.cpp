@@ -130,7 +130,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     std::vector<float> rec;
     make_records(n, rec);
     if (gs4d_create(local_rank, a.width, a.height, &ctx) != GS4D_OK) { fprintf(stderr, "[rank %d] gs4d_create: %s\n", rank, gs4d_last_error(nullptr)); return 1; }
-    GSOK(gs4d_set_stream(ctx, stream));
+    if (!getenv("GS4D_SWEEP_EXPERIMENT_NO_STREAM")) GSOK(gs4d_set_stream(ctx, stream));
     uint64_t st[8];
     GSOK(gs4d_get_stats(ctx, st));
     const int lanes = (int)(st[6] & 0xFFFFFFFFu);
@@ -157,9 +157,9 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     const int G = a.gather_every < 1 ? 1 : a.gather_every;
     const size_t fbytes = (size_t)a.width * a.height * 4;
     uint8_t* batch = nullptr; uint8_t* gathered = nullptr; double* dmax = nullptr;
-    HIPOK(hipMalloc(&batch, G * fbytes));
+    if (rank == 0) { HIPOK(hipMalloc(&gathered, (size_t)world * G * fbytes)); batch = gathered; }      // rank 0 packs straight into its slice of the gathered batch
+    else HIPOK(hipMalloc(&batch, G * fbytes));
     HIPOK(hipMemset(batch, 0, G * fbytes));
-    if (rank == 0) HIPOK(hipMalloc(&gathered, (size_t)world * G * fbytes));
     HIPOK(hipMalloc(&dmax, sizeof(double)));
     HIPOK(hipMemset(dmax, 0, sizeof(double)));
     std::vector<uint8_t> host_frames;                                       // verification sweep only, rank 0
@@ -183,7 +183,6 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         if (rank == 0) { for (int r = 1; r < world; ++r) NCCLOK(ncclRecv(gathered + (size_t)r * G * fbytes, G * fbytes, ncclUint8, r, comm, stream)); }
         else NCCLOK(ncclSend(batch, G * fbytes, ncclUint8, 0, comm, stream));
         NCCLOK(ncclGroupEnd());
-        if (rank == 0) HIPOK(hipMemcpyAsync(gathered, batch, G * fbytes, hipMemcpyDeviceToDevice, stream));
         if (verify && rank == 0) {
             host_frames.resize((size_t)world * G * fbytes);
             HIPOK(hipMemcpyAsync(host_frames.data(), gathered, host_frames.size(), hipMemcpyDeviceToHost, stream));
@@ -255,7 +254,8 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         fflush(stdout);
     }
     gs4d_destroy(ctx);
-    (void)hipFree(batch); (void)hipFree(gathered); (void)hipFree(dmax);
+    if (rank != 0) (void)hipFree(batch);
+    (void)hipFree(gathered); (void)hipFree(dmax);
     (void)hipStreamDestroy(stream);
     ncclCommDestroy(comm);
     if (rank == 0) unlink(idfile.c_str());

@@ -290,9 +290,13 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
     rec = gs4d.build_records_4d(pos4, q, scale, life, fade, vel, rgba)
     sc = Scene(gs4d, rec, cam, view, proj, local_rank)
     ctx = sc.ctx
-    # torch's stream becomes the caller's stream: a packed frame is ordered before the gather that sends it, and the next pack into
-    # the same slot after the gather that still reads it
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # A torch stream of our own becomes torch's current stream AND the context's caller stream: a packed frame is ordered before the
+    # gather that sends it, and the next pack into the same slot after the gather that still reads it.  (Not torch's default stream:
+    # its handle is NULL, which gs4d_set_stream reads as "no caller stream" — round 1 and early round 2 passed exactly that.)
+    comm_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(comm_stream)
+    assert comm_stream.cuda_stream != 0
+    ctx.set_stream(comm_stream.cuda_stream)
     gdev = "cuda" if backend == "nccl" else "cpu"
     G = max(1, args.gather_every)
     mine = sharding.frames_for_rank(SWEEP_FRAMES, rank, world)            # frame k -> rank k mod world
@@ -326,6 +330,29 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
         if pipelined:
             present(most - 1, 0)                          # the last frame of the sweep is presented inside the sweep
 
+    def sweep_one_gpu(_k):
+        """The same sweep with every frame on THIS GPU and nothing sent anywhere (frames packed to RGBA8 as above): the N = 1 point of the
+        strong-scaling curve of this workload (the driver's N = 1 line is a different workload: configs[1])."""
+        for k in range(SWEEP_FRAMES):
+            sc.frame(sharding.sweep_time(k, SWEEP_FRAMES))
+            if pipelined and k >= 1:
+                ctx.read_frame_rgba8_device(1, batch[(k - 1) % G].data_ptr(), H * W * 4)
+            elif not pipelined:
+                ctx.read_frame_rgba8_device(0, batch[k % G].data_ptr(), H * W * 4)
+        if pipelined:
+            ctx.read_frame_rgba8_device(0, batch[(SWEEP_FRAMES - 1) % G].data_ptr(), H * W * 4)
+
+    def fence_local():
+        ctx.finish()
+        torch.cuda.synchronize()
+
+    one_gpu = None
+    if rank == 0:
+        so = timed_windows(sweep_one_gpu, fence_local, 1, 1, 3)
+        so_ms = sorted(1e3 * x for x in so)[1]
+        one_gpu = {"ms_per_step": round(so_ms, 4), "value": n * SWEEP_FRAMES / (so_ms * 1e-3), "unit": "splats/s",
+                   "note": "the whole sweep on rank 0's GPU alone, measured by rank 0 before the distributed windows (median of 3): the N = 1 point of THIS workload"}
+
     def fence():
         ctx.finish()
         torch.cuda.synchronize()
@@ -357,6 +384,7 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
                    "frames_per_gather_per_rank": G, "frame_lanes": stats["lanes"], "tile_list_entries": stats["entries"], "overflow_reruns": stats["reruns"]},
         "roofline": {"bound": "hbm", "kernel": None, "achieved": round(frame_ach, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(frame_ach / (HBM_PEAK_GBS * world), 5),
                      "traffic": None, "note": "whole-job algorithmic bytes over all ranks against N x 8 TB/s; the per-kernel figure is in the N = 1 line"},
+        "one_gpu_same_workload": one_gpu,
         "cpu_baseline": None,
     }
 

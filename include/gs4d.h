@@ -136,10 +136,15 @@ GS4D_API int gs4d_read_pixels_rgba8_device(gs4d_ctx* ctx, void* dptr, size_t byt
  * (clear, keygen, sort, draw) never waits for frame f: its host thread stays ahead of the device.  GS4D_E_INVALID when there is no such
  * image (frames_back > 1, one frame lane, or no gs4d_clear yet). */
 GS4D_API int gs4d_read_frame_rgba8_device(gs4d_ctx* ctx, int frames_back, void* dptr, size_t bytes);
-/* Name the caller's HIP stream (hipStream_t passed as void*; NULL: none).  The library keeps running on its own streams, but from now
- * on (a) whatever the caller queued on that stream before an enqueueing call (keygen, sort, draw, device read-back) happens before the
- * work of that call — e.g. a kernel of the caller's that fills a buffer obtained with gs4d_buffer_device_ptr (see gs4d_buffer_invalidate) — and (b) whatever the
- * caller queues on it after a device read-back sees the pixels — e.g. an RCCL gather of the frames.  No host synchronisation. */
+/* Name the caller's HIP stream (hipStream_t passed as void*; NULL: none — note that the legacy default stream's handle IS NULL: give a
+ * stream of your own).  The library keeps running on its own streams, but from now on
+ *  (a) a buffer the caller rewrites on that stream (gs4d_buffer_device_ptr + gs4d_buffer_invalidate, in that call order, THEN the
+ *      caller's writes) is not used by the library before those writes are done: the first call that uses the buffer after
+ *      gs4d_buffer_invalidate records an event on the caller's stream and every frame lane waits for it before touching the buffer;
+ *  (b) a device read-back waits for what the caller queued before it (the destination may still be read by, e.g., the RCCL send of the
+ *      previous batch), and whatever the caller queues after it sees the pixels — e.g. an RCCL gather of the frames.
+ * No host synchronisation.  Calls that hand nothing over (clear, uniforms, keygen / sort / draw on buffers the caller did not announce)
+ * do not look at the caller's stream: frames keep overlapping across the lanes. */
 GS4D_API int gs4d_set_stream(gs4d_ctx* ctx, void* hip_stream);
 /* Single-frame sharding over several GPUs (secondary mode; config 5): rows of 8x8-pixel tiles are dealt round-robin,
  * tile row ty belongs to rank ty % world.  After gs4d_set_tile_shard(rank, world) a draw bins and composites only the context's own
