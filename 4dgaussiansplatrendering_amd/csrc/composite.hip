@@ -74,7 +74,8 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
     __shared__ float4 stage[64 * 3];
     __shared__ uint32_t pmask[64 * 2];                      // per pixel: 64-bit mask of the chunk entries that cover it
     if (total[1]) return;                                   // tile lists overflowed: nothing was emitted, the host re-runs
-    const uint32_t tile = blockIdx.x;
+    uint32_t tile;
+    if (!composite_tile(blockIdx.x, tiles_x, (H + TILE - 1) / TILE, tile)) return;        // uniform: padding of the XCD-aware grid
     const uint32_t lane = threadIdx.x;
     const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE;
     const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
 hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
                             int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb, int blend_src, int blend_dst) {
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
-    const dim3 grid((unsigned)(tiles_x * tiles_y));
+    const dim3 grid(composite_grid(tiles_x, tiles_y));
 #ifdef GS4D_TUNING
     static const int dbg = getenv("GS4D_COMPOSITE_DBG") ? atoi(getenv("GS4D_COMPOSITE_DBG")) : 0;   // tuning knob: 1 = broadcast only, 2 = splat-parallel only
 #else

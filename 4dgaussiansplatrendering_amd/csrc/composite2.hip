@@ -70,12 +70,13 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     __shared__ uint32_t er[64 * PER];
     float4* stage = reinterpret_cast<float4*>(sh_a);
     uint32_t* ek = sh_a;
-    const uint32_t tile = blockIdx.x;
+    uint32_t tile;
+    const bool real = composite_tile(blockIdx.x, tiles_x, (H + TILE - 1) / TILE, tile);     // false: padding of the XCD-aware grid
     const uint32_t lane = threadIdx.x;
     // what the list kernels found out — entries, longest list, abort flags — goes to the host from here (pinned, mapped memory behind
     // the lane's event): they are complete now, and none of them has to wait for a hand-off of its own
-    if (tile == 0u && lane == 0u) { total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = total[4]; total_host[1] = total[1]; }
-    if (total[1]) return;                                   // aborted draw (capacity or list length): the host re-runs it
+    if (blockIdx.x == 0u && lane == 0u) { total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = total[4]; total_host[1] = total[1]; }
+    if (total[1] || !real) return;                          // aborted draw (capacity or list length): the host re-runs it
     const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE;
     const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
@@ -153,7 +154,7 @@ hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* 
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
-    const dim3 grid((unsigned)(tiles_x * tiles_y));
+    const dim3 grid(composite_grid(tiles_x, tiles_y));
     const int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
     return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
                      : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs);

@@ -14,6 +14,25 @@ namespace gs4d {
 // Entries whose box covers more than SMALL_AREA pixels of the tile are always tested pixel-parallel.
 constexpr int SMALL_AREA = 16;
 
+// Workgroup -> tile.  Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8) and each XCD has an L2 of its own;
+// a splat that touches several tiles (1.38 entries per splat in the cube configs) is gathered once per tile.  With tile = workgroup id
+// the tiles that share a record sit on different XCDs and every gather goes to memory.  Here the image is cut into blocks of 4 x 4
+// tiles, block b belongs to XCD b % 8 (small blocks: the busy middle of the image is spread over all XCDs), and the workgroups of an
+// XCD walk its blocks one after another: neighbours in the image are neighbours in time on one L2.
+constexpr uint32_t XCDS = 8, TBLOCK = 4;
+__host__ __device__ __forceinline__ uint32_t composite_grid(int tiles_x, int tiles_y) {
+    const uint32_t nblocks = (uint32_t)((tiles_x + TBLOCK - 1) / TBLOCK) * (uint32_t)((tiles_y + TBLOCK - 1) / TBLOCK);
+    return (nblocks + XCDS - 1) / XCDS * XCDS * (TBLOCK * TBLOCK);
+}
+__device__ __forceinline__ bool composite_tile(uint32_t wg, int tiles_x, int tiles_y, uint32_t& tile) {
+    const uint32_t x = wg % XCDS, j = wg / XCDS;
+    const uint32_t block = x + XCDS * (j / (TBLOCK * TBLOCK)), t = j % (TBLOCK * TBLOCK);
+    const uint32_t bxn = (uint32_t)(tiles_x + TBLOCK - 1) / TBLOCK;
+    const uint32_t tx = (block % bxn) * TBLOCK + (t % TBLOCK), ty = (block / bxn) * TBLOCK + (t / TBLOCK);
+    tile = ty * (uint32_t)tiles_x + tx;
+    return tx < (uint32_t)tiles_x && ty < (uint32_t)tiles_y;
+}
+
 // glBlendFunc factors (GL enum values; the set the reference's menu offers, DebugMenus.h:41-59).  The reference never calls glBlendColor:
 // the blend colour stays (0, 0, 0, 0), so CONSTANT_* = 0 and ONE_MINUS_CONSTANT_* = 1.
 struct BlendFn { int sf, df; };
