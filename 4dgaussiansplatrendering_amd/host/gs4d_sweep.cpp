@@ -130,7 +130,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     std::vector<float> rec;
     make_records(n, rec);
     if (gs4d_create(local_rank, a.width, a.height, &ctx) != GS4D_OK) { fprintf(stderr, "[rank %d] gs4d_create: %s\n", rank, gs4d_last_error(nullptr)); return 1; }
-    if (!getenv("GS4D_SWEEP_EXPERIMENT_NO_STREAM")) GSOK(gs4d_set_stream(ctx, stream));
+    GSOK(gs4d_set_stream(ctx, stream));
     uint64_t st[8];
     GSOK(gs4d_get_stats(ctx, st));
     const int lanes = (int)(st[6] & 0xFFFFFFFFu);
