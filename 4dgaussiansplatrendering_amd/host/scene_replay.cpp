@@ -140,14 +140,18 @@ int main(int argc, char** argv) {
                 char name[512]; std::snprintf(name, sizeof name, "%s_%04d.png", png, index);
                 if (gs4d_host_write_png(name, host8.data(), W, H) != 0) throw std::runtime_error(std::string("cannot write ") + name);
             };
+            uint64_t st[8] = { 0 };
+            gs4d::compat::Check(gs4d_get_stats(ctx, st), "gs4d_get_stats");
+            const bool swap_chain = (st[6] & 0xFFFFFFFFu) >= 2;                    // one frame lane (GS4D_LANES=1): no previous image is kept, present the current one
             for (int f = 0; f < frames; ++f) {                                     // Application.cpp:145-190
+                if (png && !swap_chain && f > 0) present(0, f - 1);                // no swap chain: the finished image goes out before Clear() starts the next one
                 renderer.Clear();
                 cam.HandleInput(&window);
                 glBlendFunc(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA);
                 glEnable(GL_BLEND); glDisable(GL_DEPTH_TEST);
                 if (f > 0) scene.m_time += dt;                                     // Update(): m_time += m_time_speed (Scenes.h:346)
                 scene.Render();
-                if (png && f > 0) present(1, f - 1);                               // the previous image of the swap chain
+                if (png && swap_chain && f > 0) present(1, f - 1);                 // the previous image of the swap chain
             }
             if (png) present(0, frames - 1);
             if (pbuf) gs4d_buffer_destroy(ctx, pbuf);
