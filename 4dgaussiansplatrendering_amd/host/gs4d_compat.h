@@ -212,21 +212,32 @@ public:
     }
     template <class M> void SetUniformMat4f(const std::string& name, const M& m) {
         static_assert(sizeof(M) == 64, "SetUniformMat4f expects 16 column-major floats (glm::mat4)");
-        if (m_mode < 0) return;
         const float* p = reinterpret_cast<const float*>(&m);
+        Keep(name, p, 16);
+        if (m_mode < 0) return;
         if (name == "uView") gs4d::compat::Check(gs4d_set_uniform_mat4(gs4d::compat::Current(), GS4D_U_VIEW, p), "SetUniformMat4f(uView)");
         else if (name == "uProj") gs4d::compat::Check(gs4d_set_uniform_mat4(gs4d::compat::Current(), GS4D_U_PROJ, p), "SetUniformMat4f(uProj)");
     }
-    // uniforms of other arities exist in the reference for the legacy per-splat shaders (Splat.h:163-247, 355-431, 584-600); accepted and ignored
-    void SetUniform1i(const std::string&, int) {}
-    void SetUniform2f(const std::string&, float, float) {}
-    void SetUniform3f(const std::string&, float, float, float) {}
-    void SetUniform4f(const std::string&, float, float, float, float) {}
-    void SetUniform2f(const std::string&, gs4d::compat::vec2) {}                  // Shader.h:47-59
-    void SetUniform3f(const std::string&, gs4d::compat::vec3) {}
-    void SetUniform4f(const std::string&, gs4d::compat::vec4) {}
-    void SetUniformMat3f(const std::string&, gs4d::compat::mat3) {}               // Shader.h:64-68
-    void SetUniformMat2f(const std::string&, gs4d::compat::mat2) {}
+    // Uniforms of other arities exist in the reference for the legacy per-splat shaders (Splat.h:163-247, 355-431, 584-600).  No pipeline
+    // of this path consumes them; the last value given to each name is kept and can be read back (LastUniform) — that is how
+    // oracle/ref/refdraw_main.cpp observes what the reference's Splat4D::Draw / Splat3D::Draw compute on the CPU.
+    void SetUniform1i(const std::string& n, int v) { const float f[1] = { (float)v }; Keep(n, f, 1); }
+    void SetUniform2f(const std::string& n, float a, float b) { const float f[2] = { a, b }; Keep(n, f, 2); }
+    void SetUniform3f(const std::string& n, float a, float b, float c) { const float f[3] = { a, b, c }; Keep(n, f, 3); }
+    void SetUniform4f(const std::string& n, float a, float b, float c, float d) { const float f[4] = { a, b, c, d }; Keep(n, f, 4); }
+    void SetUniform2f(const std::string& n, gs4d::compat::vec2 v) { Keep(n, &v[0], 2); }                  // Shader.h:47-59
+    void SetUniform3f(const std::string& n, gs4d::compat::vec3 v) { Keep(n, &v[0], 3); }
+    void SetUniform4f(const std::string& n, gs4d::compat::vec4 v) { Keep(n, &v[0], 4); }
+    void SetUniformMat3f(const std::string& n, gs4d::compat::mat3 m) { Keep(n, &m[0][0], 9); }            // Shader.h:64-68
+    void SetUniformMat2f(const std::string& n, gs4d::compat::mat2 m) { Keep(n, &m[0][0], 4); }
+    // not in the reference: the last value set for `name` (up to 16 floats); returns the number of floats it had, 0 if it was never set
+    int LastUniform(const std::string& name, float* out, int max_floats) const {
+        const auto it = m_last.find(name);
+        if (it == m_last.end()) return 0;
+        for (int i = 0; i < it->second.n && i < max_floats; ++i) out[i] = it->second.v[i];
+        return it->second.n;
+    }
+    void ForgetUniforms() { m_last.clear(); }
     static bool TryCompile(std::string, ShaderType) { return true; }               // no GLSL is compiled on this path
     void DispatchCompute(unsigned int, unsigned int, unsigned int) {}
     void DispatchCompute(unsigned int, unsigned int) {}
@@ -237,9 +248,12 @@ public:
     size_t GetShaderSourceSize() { return m_sources.size(); }
     int Mode() const { return m_mode; }
 private:
+    struct Kept { int n = 0; float v[16] = { 0 }; };
+    void Keep(const std::string& name, const float* f, int n) { Kept k; k.n = n; for (int i = 0; i < n && i < 16; ++i) k.v[i] = f[i]; m_last[name] = k; }
     int m_mode = -1;
     bool m_lines = false;
     std::vector<ShaderSource> m_sources;
+    std::unordered_map<std::string, Kept> m_last;
 };
 
 // ---- vertex-side wrappers: API shape only (the unit quad of Geometry.h:44-50 is built into the rasteriser) -----

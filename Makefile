@@ -17,7 +17,7 @@ STRICT   := -ffp-contract=off
 
 OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(CSRC)/tilelist.o $(CSRC)/composite2.o $(CSRC)/lines.o $(HOST)/gs4d_host.o
 
-.PHONY: all lib oracle ref refscene clean demo sweep
+.PHONY: all lib oracle ref refscene refdraw clean demo sweep
 all: lib oracle demo sweep
 DEMO := $(HOST)/scene_replay
 SWEEP := $(HOST)/gs4d_sweep
@@ -50,6 +50,8 @@ ref:
 	$(MAKE) -C oracle ref
 refscene: lib
 	$(MAKE) -C oracle refscene
+refdraw: lib
+	$(MAKE) -C oracle refdraw
 
 clean:
 	rm -f $(OBJS) $(LIB) $(DEMO) $(SWEEP)

@@ -7,3 +7,6 @@ REF="${REF:-/root/reference}"
 make -C "$HERE" ref REF="$REF"
 mkdir -p "$HERE/../tests/golden"
 "$HERE/_ref/refgen" "$REF" "$HERE/../tests/golden"
+# family (8): the reference's Splat4D::Draw / Splat3D::Draw on the CPU (oracle/ref/refdraw_main.cpp); reads the records refgen just wrote
+make -C "$HERE" refdraw REF="$REF"
+"$HERE/_ref/refdraw" "$REF" "$HERE/../tests/golden"

@@ -50,8 +50,10 @@ def _f32(a):
 
 
 def golden(name):
-    with open(os.path.join(GOLDEN_DIR, "manifest.json")) as f:
-        man = json.load(f)
+    man = {}
+    for mf in ("manifest.json", "manifest_draw.json"):      # refgen's fixtures; refdraw's (oracle/ref/refdraw_main.cpp)
+        with open(os.path.join(GOLDEN_DIR, mf)) as f:
+            man.update(json.load(f))
     ent = man[name]
     if not isinstance(ent, dict) or "dtype" not in ent:
         return ent
