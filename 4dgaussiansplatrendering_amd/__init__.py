@@ -67,6 +67,7 @@ def _load():
         "gs4d_read_pixels_device": (i32, [vp, vp, sz]),
         "gs4d_read_pixels_rgba8_device": (i32, [vp, vp, sz]),
         "gs4d_read_frame_rgba8_device": (i32, [vp, i32, vp, sz]),
+        "gs4d_read_frame_rgba8_device_after": (i32, [vp, i32, vp, sz, vp]),
         "gs4d_set_tile_shard": (i32, [vp, i32, i32]),
         "gs4d_band_rows": (i32, [vp, vp]),
         "gs4d_read_band_rgba8_device": (i32, [vp, vp, sz]),
@@ -441,6 +442,11 @@ class Context:
         """Pack the current (0) or the previous (1) image of the swap chain to RGBA8 at device pointer `dptr`, asynchronously."""
         self._chk(_lib.gs4d_read_frame_rgba8_device(self._h, frames_back, C.c_void_p(dptr), nbytes))
 
+    def read_frame_rgba8_device_after(self, frames_back, dptr, nbytes, hip_event=None):
+        """As read_frame_rgba8_device, but the pack waits only for `hip_event` (a hipEvent_t handle; None: for nothing) instead of for
+        everything queued on the caller's stream: for callers that alternate between destination buffers."""
+        self._chk(_lib.gs4d_read_frame_rgba8_device_after(self._h, frames_back, C.c_void_p(dptr), nbytes, C.c_void_p(hip_event or 0)))
+
     def set_tile_shard(self, rank, world):
         """Single-frame sharding: this context bins and composites the tile rows ty % world == rank only."""
         self._chk(_lib.gs4d_set_tile_shard(self._h, rank, world))
@@ -486,7 +492,7 @@ class Context:
     def stats(self):
         st = np.zeros(8, np.uint64)
         self._chk(_lib.gs4d_get_stats(self._h, _ptr(st)))
-        return {"entries": int(st[0]), "capacity": int(st[1]), "reruns": int(st[2]), "tiles": int(st[3]),
+        return {"entries": int(st[0]), "capacity": int(st[1]), "reruns": int(st[2]) & 0xFFFFFFFF, "aborted_discarded": int(st[2]) >> 32, "tiles": int(st[3]),
                 "depth_sort_passes": int(st[4]), "tile_sort_passes": int(st[5]), "lanes": int(st[6]) & 0xFFFFFFFF, "fused_keygen_draws": int(st[6]) >> 32,
                 "unordered_draws": int(st[7]) & 0xFFFFFFFF, "longest_list": int(st[7]) >> 32}
 

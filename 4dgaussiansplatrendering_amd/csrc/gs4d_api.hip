@@ -68,12 +68,19 @@ struct DrawArgs {
     // the draw also executes the gs4d_keygen + gs4d_sort_pairs that were queued for it (first run only: a re-run finds the buffers sorted)
     bool fuse = false; gs4d_buf fuse_keys = 0, fuse_idx = 0; uint32_t fuse_span = 0xFFFFFFFFu;
     int blend_src = GS4D_SRC_ALPHA, blend_dst = GS4D_ONE_MINUS_SRC_ALPHA;       // glBlendFunc state at the draw
+    float clear[4] = { 0, 0, 0, 0 };   // what "clear" meant for the image when the draw was issued (a re-run must not pick up a later glClearColor)
+    int shard_rank = 0, shard_world = 1;       // ... and the tile-row shard
+    // The re-run of an unordered draw on the ordered path: the draw never read the caller's sort index (it took its order from the keys), and by
+    // now the application may have overwritten it for a later frame.  The re-run regenerates "records in ascending (key, index)" from `ks`
+    // into the lane's private index instead of reading the caller's buffer.
+    bool regen_order = false;
 };
 
 struct Framebuffer {
     float4* mem = nullptr;
     uint32_t* linecnt = nullptr;   // per-pixel fragment counters of the overlay-line kernels (lines.hip), allocated on first use, all-zero between calls
     bool is_clear = true;          // content == clear colour, not yet materialised
+    float clear[4] = { 0, 0, 0, 0 };   // that colour: the context's clear colour at the gs4d_clear that cleared this image
     int last_lane = -1;            // lane that touched it last
 };
 
@@ -86,6 +93,7 @@ struct Lane {
     uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;   // tile-list entries: one allocation of 8 * pair_cap bytes — (tile ids | records) on the ordered path, (key, record) pairs on the unordered one
     TileLists tl;                      // unordered path: per-tile counts / starts / cursors, per-record blend keys
     uint32_t* order_copy = nullptr; size_t order_cap = 0;   // private copy of the last draw's sort index (for a re-run after overflow)
+    uint32_t* regen_keys = nullptr; size_t regen_cap = 0;   // keys of a regenerated sort index (DrawArgs::regen_order), allocated on first use
     SortScratch depth_sort, pair_sort;
     BinScratch bin;
     float* line_verts = nullptr; size_t line_cap = 0;   // device copy of the vertices of the latest gs4d_draw_lines (the lane's stream orders its reuse)
@@ -94,6 +102,7 @@ struct Lane {
     gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
     gs4d_buf kg_idx = 0, kg_data = 0; uint64_t kg_idx_ver = 0, kg_data_ver = 0; KeySrc kg_ks; int kg_bits = 32;   // ... the identity index it wrote beside them, and what the keys were computed from
     bool pending = false;              // the lane's last draw has not had its tile-list capacity validated yet
+    bool discarded = false;            // ... and its image has been cleared since: validated (counted, learned from) but never re-run
     DrawArgs pending_args;
 };
 
@@ -122,6 +131,7 @@ struct gs4d_ctx {
     int shard_rank = 0, shard_world = 1;   // single-frame sharding: this context bins and composites the tile rows ty % world == rank
     int prev_fb = -1;                  // the image the last gs4d_clear moved away from (still intact until its lane comes round again)
     uint64_t stat_entries = 0, stat_reruns = 0, stat_depth_passes = 0, stat_tile_passes = 0;
+    uint64_t stat_aborted_discarded = 0;   // draws that aborted on the device (capacity, list length) and were cleared away before anybody observed them
     // draw path selection: the unordered path needs lists short enough to be sorted in LDS (<= V2_MAX_LIST entries per tile)
     int path_pref = 0;                 // GS4D_DRAW_PATH: 0 auto, 1 ordered path only, 2 = auto (kept for symmetry)
     bool long_lists = false;           // the last unordered draw met a list longer than V2_MAX_LIST: draws use the ordered path ...
@@ -158,7 +168,7 @@ int hipfail(gs4d_ctx* c, hipError_t e, const char* where) {
 }
 #define HIPCHK(c, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hipfail((c), e__, #call); } while (0)
 
-const char* const DEVICE_CHECK_MSG = "device-side check failed (a bounded look-back wait timed out, or a sort key fell outside its proven bounds): results are invalid";
+const char* const DEVICE_CHECK_MSG = "device-side check failed (a bounded look-back wait timed out, a sort key fell outside its proven bounds, or a key buffer changed under a queued sort without gs4d_buffer_invalidate): results are invalid";
 
 Buffer* getbuf(gs4d_ctx* c, gs4d_buf b) { return (b != 0 && b < c->bufs.size() && c->bufs[b].alive) ? &c->bufs[b] : nullptr; }
 Lane& lane(gs4d_ctx* c) { return c->lanes[c->cur]; }
@@ -214,13 +224,9 @@ int after_user_fill(gs4d_ctx* c, Buffer& B) {
 }
 int lane_access(gs4d_ctx* c, Buffer& B, bool write) {
     { int rc = after_user_fill(c, B); if (rc) return rc; }
-    if (write) {
-        // An unordered draw never read its sort index — but if its validation fails it is re-run on the ordered path, which does.
-        // Validate such draws before the index they were given is overwritten (in steady state their event completed long ago).
-        const gs4d_buf id = (gs4d_buf)(&B - c->bufs.data());
-        for (int i = 0; i < c->nlanes; ++i)
-            if (c->lanes[i].pending && c->lanes[i].pending_args.v2 && c->lanes[i].pending_args.order == id) { int rc = resolve_lane(c, i); if (rc) return rc; }
-    }
+    // (An unordered draw never read its sort index, and its re-run does not either — DrawArgs::regen_order — so overwriting the index a
+    // still-unvalidated draw was given needs no validation first: an application with ONE key / index buffer pair, the reference's layout
+    // (Scenes.h m_key_buf / m_values_buf), is ordered lane after lane on the device by the events below, never on the host.)
     Lane& L = lane(c);
     const unsigned me = 1u << c->cur;
     if (B.wr_lane >= 0 && B.wr_lane != c->cur && !(B.ordered_mask & me)) {
@@ -290,14 +296,15 @@ int materialise_fb(gs4d_ctx* c) {
     Framebuffer& F = c->fbs[c->cur_fb];
     if (F.is_clear) {
         int rc = fb_access(c, F); if (rc) return rc;
-        HIPCHK(c, launch_fill(lane(c).s, F.mem, (size_t)c->W * c->H, c->clear));
+        HIPCHK(c, launch_fill(lane(c).s, F.mem, (size_t)c->W * c->H, F.clear));
         F.is_clear = false;
     }
     return GS4D_OK;
 }
 
 // Enqueue binning -> tile sort -> ranges -> composite for the projected records in L.proj.
-int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c, bool fb_was_clear, int blend_src, int blend_dst) {
+int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c) {
+    const bool fb_was_clear = a.fb_was_clear; const int blend_src = a.blend_src, blend_dst = a.blend_dst;
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
@@ -307,7 +314,7 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, 
         uint32_t* ph = sort_hist_slot(L.s, L.pair_sort, L.pair_cap, &he);      // the emit kernel also counts the tile-id digits
         if (!ph) return hipfail(c, he, "sort_hist_slot");
         HIPCHK(c, launch_binning(L.s, L.bin, L.rects, order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, L.pair_keys, L.pair_vals, L.pair_cap, L.host_total_dev + 4,
-                                 ph, tile_passes, L.host_total_dev, c->shard_rank, c->shard_world));
+                                 ph, tile_passes, L.host_total_dev, a.shard_rank, a.shard_world));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));     // the last binning workgroup wrote the total straight into pinned host memory
     {
@@ -318,7 +325,7 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const uint32_t* order, 
     {
         StageTimer t(c, GS4D_T_COMPOSITE);      // the per-tile ranges and the compositing kernel
         HIPCHK(c, launch_tile_ranges(L.s, L.bin, L.pair_keys, L.pair_cap, ntiles));
-        HIPCHK(c, launch_composite(L.s, L.proj, L.pair_vals, L.bin.ranges, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, c->clear, F.mem, blend_src, blend_dst));
+        HIPCHK(c, launch_composite(L.s, L.proj, L.pair_vals, L.bin.ranges, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, a.clear, F.mem, blend_src, blend_dst));
     }
     return GS4D_OK;
 }
@@ -331,14 +338,14 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
     {
         StageTimer t(c, GS4D_T_BINNING);
         HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
-        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, tmp, c->tiles_x, c->shard_rank, c->shard_world));
+        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world));
         HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
     }
     c->stat_tile_passes = 0;
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
         int recbits = 1; while (recbits < 32 && ((size_t)1 << recbits) < nrecords) ++recbits;
-        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, c->clear, F.mem,
+        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem,
                                       c->list_hint, a.keybits, recbits, L.tl.slabs));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event (the compositor's first workgroup wrote them)
@@ -357,10 +364,12 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     int premult = 0;
     if (a.quads) { nrec = data->bytes / 288; npre = nrec < a.instances ? nrec : a.instances; premult = 1; }
     else if (a.mode == GS4D_MODE_4D_SORTED) {
-        ob = getbuf(c, a.order);
-        if (!ob) return fail(c, GS4D_E_INVALID, "draw: GS4D_MODE_4D_SORTED needs the sort-index buffer at slot 1");
-        if (ob->bytes < a.instances * 4) return fail(c, GS4D_E_INVALID, "draw: sort-index buffer smaller than the instance count");
-        order = (const uint32_t*)ob->d;
+        if (!a.regen_order) {
+            ob = getbuf(c, a.order);
+            if (!ob) return fail(c, GS4D_E_INVALID, "draw: GS4D_MODE_4D_SORTED needs the sort-index buffer at slot 1");
+            if (ob->bytes < a.instances * 4) return fail(c, GS4D_E_INVALID, "draw: sort-index buffer smaller than the instance count");
+            order = (const uint32_t*)ob->d;
+        }
         nrec = data->bytes / 96; npre = nrec;
     } else if (a.mode == GS4D_MODE_4D_DIRECT) { nrec = data->bytes / 96; npre = nrec < a.instances ? nrec : a.instances; }
     else if (a.mode == GS4D_MODE_2D) { nrec = data->bytes / 48; npre = nrec < a.instances ? nrec : a.instances; }
@@ -372,7 +381,8 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, c->slabs, a.keybits);
     if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
     uint32_t* order_copy = nullptr;
-    if (order) {
+    const bool regen = a.regen_order && !v2 && a.mode == GS4D_MODE_4D_SORTED && !a.quads;
+    if (order || regen) {
         if (L.order_cap < a.instances) {
             HIPCHK(c, hipStreamSynchronize(L.s));
             if (L.order_copy) (void)hipFree(L.order_copy);
@@ -380,7 +390,8 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             HIPCHK(c, hipMalloc(&L.order_copy, a.instances * 4));
             L.order_cap = a.instances;
         }
-        if (preprocess) order_copy = L.order_copy;        // first run: the emit kernel reads the caller's buffer and keeps a copy
+        if (regen) order = L.order_copy;                   // filled below (first re-run) or by an earlier re-run of this draw
+        else if (preprocess) order_copy = L.order_copy;   // first run: the emit kernel reads the caller's buffer and keeps a copy
         else order = L.order_copy;                         // re-run: the caller's buffer may have been overwritten since
     }
     if (preprocess) {
@@ -399,7 +410,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             StageTimer t(c, GS4D_T_PREPROCESS);
             const PreOut po = { L.proj, L.rects };
             TileCount tc;
-            if (v2) { tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.rows = L.tl.rows; tc.tiles_x = c->tiles_x; tc.shard_rank = c->shard_rank; tc.shard_world = c->shard_world; tc.ks = a.ks; }
+            if (v2) { tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.rows = L.tl.rows; tc.tiles_x = c->tiles_x; tc.shard_rank = a.shard_rank; tc.shard_world = a.shard_world; tc.ks = a.ks; }
             if (a.fuse) {
                 tc.ks = a.ks;
                 Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
@@ -415,6 +426,26 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, data->soa_n, npre, a.u, c->W, c->H, po, tc));
         }
         L.proj_n = npre;
+        if (regen) {
+            // "records in ascending (depth key, record index)" — what the caller's index held when the draw was issued — from the key source
+            // the draw carries: k_keygen + the stable sort, into the lane's own buffers
+            if (L.regen_cap < npre) {
+                HIPCHK(c, hipStreamSynchronize(L.s));
+                if (L.regen_keys) (void)hipFree(L.regen_keys);
+                L.regen_keys = nullptr; L.regen_cap = 0;
+                HIPCHK(c, hipMalloc(&L.regen_keys, npre * 4));
+                L.regen_cap = npre;
+            }
+            hipError_t he = hipSuccess;
+            uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, npre, &he);
+            if (!kh) return hipfail(c, he, "sort_hist_slot");
+            const float cam[3] = { a.ks.camx, a.ks.camy, a.ks.camz };
+            float view[16] = { 0 }; view[2] = a.ks.vr0; view[6] = a.ks.vr1; view[10] = a.ks.vr2; view[14] = a.ks.vr3;
+            HIPCHK(c, launch_keygen(L.s, data->soa, data->soa + 5 * data->soa_n, npre, a.ks.t, cam, view, a.ks.mode == KEYSRC_VIEWZ ? GS4D_KEY_VIEW_Z : GS4D_KEY_REF_INV_EUCLID,
+                                    (float*)L.regen_keys, L.order_copy, kh, a.ks.bias, 0xFFFFFFFFu, L.host_total_dev + 4));
+            L.depth_sort.hist_bias = a.ks.bias;
+            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, L.regen_keys, L.order_copy, npre, nullptr, a.keybits, true));
+        }
         { int rc = fb_access(c, F); if (rc) return rc; }
         if (a.fuse && !v2) {
             // ordered path: the sort the application asked for runs here, between the projection (which wrote its keys and digit
@@ -438,7 +469,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
         }
         return rc;
     }
-    return enqueue_raster(c, L, F, order, order_copy, a.instances, npre, premult, a.fb_was_clear, a.blend_src, a.blend_dst);
+    return enqueue_raster(c, L, F, a, order, order_copy, a.instances, npre, premult);
 }
 
 // A draw's tile-list capacity is validated after the fact: the entry count comes back through pinned memory behind an event.
@@ -449,6 +480,8 @@ int resolve_lane(gs4d_ctx* c, int li) {
     while (L.pending) {
         HIPCHK(c, hipEventSynchronize(L.ev_emit));     // the entry count is final once the binning kernel (ordered path) / the tile scan (unordered path) has run
         L.pending = false;
+        const bool discarded = L.discarded;             // the image was cleared before anybody looked: learn from the draw, do not repeat it
+        L.discarded = false;
         if (L.host_total[4]) return fail(c, GS4D_E_DEVICE, DEVICE_CHECK_MSG);
         const uint64_t total = (uint64_t)L.host_total[2] | ((uint64_t)L.host_total[3] << 32);
         const uint32_t flags = L.host_total[1];
@@ -460,8 +493,8 @@ int resolve_lane(gs4d_ctx* c, int li) {
             if (!flags && c->slabs > 1u && L.host_total[5] * 3u < V2_MAX_LIST) { if (++c->unslab_votes >= 16) { c->slabs /= 2u; c->list_hint = V2_MAX_LIST; c->unslab_votes = 0; } } else c->unslab_votes = 0;
         }
         if (!flags) { c->stat_entries = total; break; }
-        if (total >= 0xFFFFFFF0ull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)");
-        c->stat_reruns++;
+        if (total >= 0xFFFFFFF0ull) { if (discarded) break; return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)"); }
+        if (discarded) c->stat_aborted_discarded++; else c->stat_reruns++;
         c->stat_entries = total;
         const bool was_v2 = L.pending_args.v2;     // an unordered draw kept no copy of its sort index: whatever path the re-run takes, it starts from the projection
         if (L.pending_args.v2 && (flags & 2u)) {
@@ -476,15 +509,19 @@ int resolve_lane(gs4d_ctx* c, int li) {
                 while (want < V2_MAX_SLABS && (uint64_t)longest * launched > (uint64_t)want * (V2_MAX_LIST - V2_MAX_LIST / 4u) && (want * 2u) <= (1u << std::min(30, L.pending_args.keybits))) want *= 2u;
                 const bool helps = (uint64_t)longest * launched <= (uint64_t)want * V2_MAX_LIST && want > launched;
                 if (helps) { c->slabs = std::max(c->slabs, want); c->list_hint = V2_MAX_LIST; }
-                else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; }
+                else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; L.pending_args.regen_order = true; }
             }
         }
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;
+        if (discarded) break;                           // the lane's next draw starts with what this one found out
         // the re-run goes to the draw's own lane: make it current while its kernels are queued
         const int saved = c->cur;
         c->cur = li;
         rc = run_draw(c, L.pending_args, was_v2);
+        // Other lanes order themselves after this lane through its tail event (fb_access, lane_access), which was recorded when the lane was
+        // left — before this re-run.  Record it again so that it keeps covering everything queued on the lane.
+        if (rc == GS4D_OK && li != saved) { hipError_t he = hipEventRecord(L.ev_tail, L.s); if (he != hipSuccess) { c->cur = saved; return hipfail(c, he, "hipEventRecord"); } }
         c->cur = saved;
         if (rc) return rc;
         L.pending = true;
@@ -547,7 +584,7 @@ int alloc_fbs(gs4d_ctx* c, int w, int h) {
         if (c->fbs[i].mem) { (void)hipFree(c->fbs[i].mem); c->fbs[i].mem = nullptr; }
         if (c->fbs[i].linecnt) { (void)hipFree(c->fbs[i].linecnt); c->fbs[i].linecnt = nullptr; }
         HIPCHK(c, hipMalloc(&c->fbs[i].mem, (size_t)w * h * 16));
-        c->fbs[i].is_clear = true; c->fbs[i].last_lane = -1;
+        c->fbs[i].is_clear = true; c->fbs[i].last_lane = -1; memcpy(c->fbs[i].clear, c->clear, 16);
     }
     c->W = w; c->H = h; c->tiles_x = (w + TILE - 1) / TILE; c->tiles_y = (h + TILE - 1) / TILE;
     c->cur_fb = c->cur; c->prev_fb = -1;
@@ -617,6 +654,7 @@ void gs4d_destroy(gs4d_ctx* c) {
         if (c->fbs[i].linecnt) (void)hipFree(c->fbs[i].linecnt);
         if (L.line_verts) (void)hipFree(L.line_verts);
         if (L.order_copy) (void)hipFree(L.order_copy);
+        if (L.regen_keys) (void)hipFree(L.regen_keys);
         if (L.proj) (void)hipFree(L.proj);
         if (L.rects) (void)hipFree(L.rects);
         if (L.pair_keys) (void)hipFree(L.pair_keys);
@@ -770,8 +808,8 @@ int gs4d_set_uniform_mat4(gs4d_ctx* c, int id, const float m[16]) {
 int gs4d_set_clear_color(gs4d_ctx* c, const float rgba[4]) {
     if (!c || !rgba) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
-    if (c->fbs[c->cur_fb].is_clear && memcmp(c->clear, rgba, 16) != 0) { int rc = materialise_fb(c); if (rc) return rc; }  // glClearColor does not touch pixels
-    memcpy(c->clear, rgba, 16); return GS4D_OK;
+    memcpy(c->clear, rgba, 16);          // glClearColor does not touch pixels: an image that is (lazily) clear keeps the colour it was cleared with (Framebuffer::clear)
+    return GS4D_OK;
 }
 int gs4d_set_blend(gs4d_ctx* c, int src, int dst) {
     if (!c) return GS4D_E_INVALID;
@@ -791,8 +829,11 @@ int gs4d_clear(gs4d_ctx* c) {
     else if (c->nlanes == 1) c->prev_fb = -1;
     c->cur_fb = c->cur;
     c->fbs[c->cur_fb].is_clear = true;
-    // whatever a still-unvalidated draw left in the image that is being cleared is discarded with it
-    for (int i = 0; i < c->nlanes; ++i) if (c->lanes[i].pending && c->lanes[i].pending_args.fb == c->cur_fb) c->lanes[i].pending = false;
+    memcpy(c->fbs[c->cur_fb].clear, c->clear, 16);
+    // Whatever a still-unvalidated draw left in the image that is being cleared is discarded with it — the draw is never re-run — but its
+    // verdict is still read (resolve_lane, at the latest when its lane draws again): what it found out about the scene's lists feeds the next
+    // draw, and a draw that had aborted on the device is counted (gs4d_get_stats: a frame loop that never reads back can prove its frames complete).
+    for (int i = 0; i < c->nlanes; ++i) if (c->lanes[i].pending && c->lanes[i].pending_args.fb == c->cur_fb) c->lanes[i].discarded = true;
     return GS4D_OK;
 }
 
@@ -911,6 +952,8 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     Lane& L = lane(c);
     a.lane = c->cur; a.fb = c->cur_fb;
     a.fb_was_clear = c->fbs[c->cur_fb].is_clear;
+    memcpy(a.clear, c->fbs[c->cur_fb].clear, 16);
+    a.shard_rank = c->shard_rank; a.shard_world = c->shard_world;
     // Which path: the unordered one whenever the blend order is known without reading a sort index — instance k draws record k, or the
     // bound index is this library's sort of its own depth keys for exactly these records — and the lists are short enough to be
     // ordered in LDS (validated on the device; a draw that turns out otherwise is re-run on the ordered path).
@@ -1046,7 +1089,7 @@ int gs4d_read_pixels(gs4d_ctx* c, float* rgba, size_t bytes) {
 // frames_back 0: the image the last clear / draw used.  1: the image the last gs4d_clear moved away from (the previous frame of the
 // swap chain) — it is packed on the lane that rendered it, behind its compositing kernel, so an application that reads frame f-1
 // after queueing frame f never waits for frame f.
-static int read_device_common(gs4d_ctx* c, int frames_back, void* dptr, bool rgba8) {
+static int read_device_common(gs4d_ctx* c, int frames_back, void* dptr, bool rgba8, bool named_event = false, hipEvent_t after = nullptr) {
     if (frames_back != 0 && frames_back != 1) return fail(c, GS4D_E_INVALID, "read_frame: frames_back must be 0 or 1");
     const int fi = frames_back == 0 ? c->cur_fb : c->prev_fb;
     if (fi < 0) return fail(c, GS4D_E_INVALID, "read_frame: no previous image is retained (one frame lane, or no gs4d_clear yet)");
@@ -1054,12 +1097,13 @@ static int read_device_common(gs4d_ctx* c, int frames_back, void* dptr, bool rgb
     Framebuffer& F = c->fbs[fi];
     const int li = (fi == c->cur_fb || F.last_lane < 0) ? c->cur : F.last_lane;
     Lane& L = c->lanes[li];
-    if (c->user) {                                          // the destination may still be in use by the caller's earlier work
+    if (named_event) { if (after) HIPCHK(c, hipStreamWaitEvent(L.s, after, 0)); }      // the caller says exactly what the destination has to wait for
+    else if (c->user) {                                     // the destination may still be in use by the caller's earlier work
         HIPCHK(c, hipEventRecord(c->ev_user, c->user));
         HIPCHK(c, hipStreamWaitEvent(L.s, c->ev_user, 0));
     }
     if (li == c->cur) { rc = fb_access(c, F); if (rc) return rc; }
-    if (F.is_clear) { HIPCHK(c, launch_fill(L.s, F.mem, (size_t)c->W * c->H, c->clear)); F.is_clear = false; }
+    if (F.is_clear) { HIPCHK(c, launch_fill(L.s, F.mem, (size_t)c->W * c->H, F.clear)); F.is_clear = false; }
     if (rgba8) HIPCHK(c, launch_pack_rgba8(L.s, F.mem, (size_t)c->W * c->H, (uint32_t*)dptr));
     else HIPCHK(c, hipMemcpyAsync(dptr, F.mem, (size_t)c->W * c->H * 16, hipMemcpyDeviceToDevice, L.s));
     if (li != c->cur) HIPCHK(c, hipEventRecord(L.ev_tail, L.s));      // the lane's tail event keeps covering everything queued on it
@@ -1092,6 +1136,14 @@ int gs4d_read_frame_rgba8_device(gs4d_ctx* c, int frames_back, void* dptr, size_
     { int rcq = flush_order(c); if (rcq) return rcq; }
     if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_frame_rgba8_device: bytes != width*height*4");
     return read_device_common(c, frames_back, dptr, true);
+}
+
+int gs4d_read_frame_rgba8_device_after(gs4d_ctx* c, int frames_back, void* dptr, size_t bytes, void* hip_event) {
+    if (!c || !dptr) return GS4D_E_INVALID;
+    (void)hipSetDevice(c->device);
+    { int rcq = flush_order(c); if (rcq) return rcq; }
+    if (bytes != (size_t)c->W * c->H * 4) return fail(c, GS4D_E_INVALID, "read_frame_rgba8_device_after: bytes != width*height*4");
+    return read_device_common(c, frames_back, dptr, true, true, (hipEvent_t)hip_event);
 }
 
 static int band_pixel_rows(const gs4d_ctx* c) {
@@ -1209,7 +1261,7 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     if (!c || !stats) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = c->stat_reruns; stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
+    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
     stats[4] = c->stat_depth_passes; stats[5] = c->stat_tile_passes; stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }

@@ -446,6 +446,11 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
                 // this XCD's L2 until the end-of-kernel write-back.  Large sorts (the 8192-key shape, several rounds of tiles per workgroup):
                 // ordinary stores, so that the L2 merges the partial lines at the ends of neighbouring runs before they reach HBM — measured
                 // at 10^7 keys: 75.7 -> 57.7 us per pass; at 10^6 keys the streaming form is the faster one (14.1 against 15.8).
+                // `o` is built from the global digit histograms, which an EARLIER kernel accumulated (k_keygen, the projection, k_os_hist), and
+                // from this launch's own counts: if the keys changed in between — a caller refilling the buffer through a device pointer
+                // without gs4d_buffer_invalidate — the two no longer describe the same array and `o` can point anywhere.  One compare keeps
+                // the store inside the buffer and turns the contract violation into the error word (the frame is reported as failed).
+                if (o >= n) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); continue; }
                 if (ITEMS >= 16) { keys_out[o] = k; vals_out[o] = svals[l]; }
                 else { __builtin_nontemporal_store(k, keys_out + o); __builtin_nontemporal_store(svals[l], vals_out + o); }
             }

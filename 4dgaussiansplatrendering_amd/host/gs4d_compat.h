@@ -219,8 +219,8 @@ public:
         else if (name == "uProj") gs4d::compat::Check(gs4d_set_uniform_mat4(gs4d::compat::Current(), GS4D_U_PROJ, p), "SetUniformMat4f(uProj)");
     }
     // Uniforms of other arities exist in the reference for the legacy per-splat shaders (Splat.h:163-247, 355-431, 584-600).  No pipeline
-    // of this path consumes them; the last value given to each name is kept and can be read back (LastUniform) — that is how
-    // oracle/ref/refdraw_main.cpp observes what the reference's Splat4D::Draw / Splat3D::Draw compute on the CPU.
+    // of this path consumes them; the last value given to each name is kept and can be read back (LastUniform) — that is how the
+    // test tree's golden-vector harness observes what the reference's Splat4D::Draw / Splat3D::Draw compute on the CPU.
     void SetUniform1i(const std::string& n, int v) { const float f[1] = { (float)v }; Keep(n, f, 1); }
     void SetUniform2f(const std::string& n, float a, float b) { const float f[2] = { a, b }; Keep(n, f, 2); }
     void SetUniform3f(const std::string& n, float a, float b, float c) { const float f[3] = { a, b, c }; Keep(n, f, 3); }

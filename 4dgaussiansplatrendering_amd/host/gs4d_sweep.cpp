@@ -9,12 +9,20 @@
 //   gs4d_sweep --gpus N            forks N ranks itself (before anything touches the GPU), rank r on device r
 //   RANK=r WORLD_SIZE=N LOCAL_RANK=l gs4d_sweep      one rank, started by a launcher of your own (MASTER_PORT names the rendezvous file)
 //
-// Rendezvous: rank 0 writes the ncclUniqueId to a file under /tmp (renamed into place), the others wait for it.
+//   gs4d_sweep --gpus N --shard-tiles   BASELINE.json configs[4]'s shape instead: ONE frame per step, its rows of 8x8 tiles dealt round-robin
+//                                  to the ranks (gs4d_set_tile_shard; every rank sorts all splats, composites its rows), bands gathered on rank 0
+//
+// Rendezvous: rank 0 writes {job nonce, ncclUniqueId} to a file under /tmp (renamed into place), the others wait for a file carrying
+// THEIR job's nonce — a file left behind by an earlier, failed job is ignored (the nonce is the launcher's run id where there is one;
+// without one, a file older than the waiting process is).
 // Presentation is software-pipelined as a swap chain is (frame j is queued first, then frame j-1 — the previous image — is packed to
 // RGBA8 into the batch) and every G presented frames the batch goes to rank 0: ncclSend / ncclRecv in one group, on a stream of this
-// program's that the context knows as the caller's stream (gs4d_set_stream): a pack waits for the gather that still reads its slot, a
-// gather for the packs it sends — by events, inside the library.  Every rank presents ceil(256 / N) times, so all ranks make the same
-// collective calls whatever the world size.
+// program's that the context knows as the caller's stream (gs4d_set_stream).  There are TWO batch buffers, used alternately: a pack
+// into one waits only for the gather that last read THAT buffer (an event of this program's, handed to
+// gs4d_read_frame_rgba8_device_after), never for the gather of the other buffer that is still in flight; a gather waits for the packs it
+// sends (inside the library).  Every rank presents ceil(256 / N) times, so all ranks make the same collective calls whatever the world size.
+// The line reports, per rank, how long the comm stream was busy per sweep (sum of its gathers: for a sender that includes waiting for
+// rank 0 to post the matching receive) and how long it ran on after the rank's last frame had been rendered (the exposed tail).
 #include "../../include/gs4d.h"
 
 #include <hip/hip_runtime_api.h>
@@ -25,7 +33,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 #include <sys/stat.h>
@@ -42,12 +52,14 @@ struct Args {
     std::string png;             // prefix: rank 0 writes <prefix>####.png for every --png-every-th frame of the verification sweep
     int png_every = 32;
     bool verify = true;          // one untimed sweep whose frames are copied to the host on rank 0 and check-summed in frame order
+    bool shard_tiles = false;    // one frame per step, tile rows sharded over the ranks (configs[4]) instead of frames (configs[3])
 };
 
 #define HIPOK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, hipGetErrorString(e_)); return 1; } } while (0)
 #define NCCLOK(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) { fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, ncclGetErrorString(r_)); return 1; } } while (0)
 #define GSOK(call) do { int r_ = (call); if (r_ != GS4D_OK) { fprintf(stderr, "[rank %d] %s: %s\n", g_rank, #call, gs4d_last_error(ctx)); return 1; } } while (0)
 int g_rank = 0;
+long g_started = 0;              // wall-clock second this process entered main()
 
 // ---- synthetic scene: the counter-based generator of tests/scenes.py (splitmix64 of seed ^ (index * 64 + stream) -> 24-bit uniforms) ----
 uint64_t splitmix64(uint64_t x) {
@@ -101,25 +113,38 @@ bool write_file(const std::string& path, const void* p, size_t bytes) {
     return ok;
 }
 
-int run_rank(const Args& a, int rank, int world, int local_rank, const std::string& idfile) {
+struct Rendezvous { char nonce[64]; ncclUniqueId id; };
+
+int sweep_tiles(const Args& a, int rank, int world, gs4d_ctx* ctx, ncclComm_t comm, hipStream_t stream, gs4d_buf data, const std::vector<gs4d_buf>& keys, const std::vector<gs4d_buf>& idx, int lanes, const float cam_pos[3]);
+
+int run_rank(const Args& a, int rank, int world, int local_rank, const std::string& idfile, const std::string& nonce) {
     g_rank = rank;
     gs4d_ctx* ctx = nullptr;
     HIPOK(hipSetDevice(local_rank));
     // ---- communicator ----
-    ncclUniqueId id;
+    Rendezvous rv;
+    memset(&rv, 0, sizeof rv);
     if (rank == 0) {
-        NCCLOK(ncclGetUniqueId(&id));
+        unlink(idfile.c_str());                                              // whatever an earlier job left there
+        NCCLOK(ncclGetUniqueId(&rv.id));
+        snprintf(rv.nonce, sizeof rv.nonce, "%s", nonce.c_str());
         const std::string tmp = idfile + ".tmp";
-        if (!write_file(tmp, &id, sizeof id) || rename(tmp.c_str(), idfile.c_str()) != 0) { fprintf(stderr, "cannot write %s\n", idfile.c_str()); return 1; }
+        if (!write_file(tmp, &rv, sizeof rv) || rename(tmp.c_str(), idfile.c_str()) != 0) { fprintf(stderr, "cannot write %s\n", idfile.c_str()); return 1; }
     } else {
         bool got = false;
         for (int tries = 0; tries < 6000 && !got; ++tries) {                  // up to 60 s
             FILE* f = fopen(idfile.c_str(), "rb");
-            if (f) { got = fread(&id, 1, sizeof id, f) == sizeof id; fclose(f); }
+            if (f) {
+                // another job's file — a different nonce, or (no job id to compare: nonce empty) a file older than this process: keep waiting
+                struct stat sb;
+                got = fread(&rv, 1, sizeof rv, f) == sizeof rv && (nonce.empty() ? (fstat(fileno(f), &sb) == 0 && (long)sb.st_mtime >= g_started - 10) : strncmp(rv.nonce, nonce.c_str(), sizeof rv.nonce) == 0);
+                fclose(f);
+            }
             if (!got) usleep(10000);
         }
-        if (!got) { fprintf(stderr, "[rank %d] no rendezvous file %s\n", rank, idfile.c_str()); return 1; }
+        if (!got) { fprintf(stderr, "[rank %d] no rendezvous file %s for job %s\n", rank, idfile.c_str(), nonce.c_str()); return 1; }
     }
+    const ncclUniqueId id = rv.id;
     ncclComm_t comm;
     NCCLOK(ncclCommInitRank(&comm, world, id, rank));
     hipStream_t stream;
@@ -149,6 +174,14 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     GSOK(gs4d_set_uniform_1f(ctx, GS4D_U_MIN_OPACITY, 0.0f));
     GSOK(gs4d_set_uniform_mat4(ctx, GS4D_U_VIEW, view));
     GSOK(gs4d_set_uniform_mat4(ctx, GS4D_U_PROJ, proj));
+    if (a.shard_tiles) {
+        const int rc = sweep_tiles(a, rank, world, ctx, comm, stream, data, keys, idx, lanes, cam_pos);
+        gs4d_destroy(ctx);
+        (void)hipStreamDestroy(stream);
+        ncclCommDestroy(comm);
+        if (rank == 0) unlink(idfile.c_str());
+        return rc;
+    }
 
     // ---- frames of this rank, batches ----
     std::vector<int> mine;
@@ -156,12 +189,22 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     const int most = (a.frames + world - 1) / world;                        // presentations per rank and sweep (rank 0 has the most frames)
     const int G = a.gather_every < 1 ? 1 : a.gather_every;
     const size_t fbytes = (size_t)a.width * a.height * 4;
-    uint8_t* batch = nullptr; uint8_t* gathered = nullptr; double* dmax = nullptr;
-    if (rank == 0) { HIPOK(hipMalloc(&gathered, (size_t)world * G * fbytes)); batch = gathered; }      // rank 0 packs straight into its slice of the gathered batch
-    else HIPOK(hipMalloc(&batch, G * fbytes));
-    HIPOK(hipMemset(batch, 0, G * fbytes));
-    HIPOK(hipMalloc(&dmax, sizeof(double)));
-    HIPOK(hipMemset(dmax, 0, sizeof(double)));
+    // two batch buffers, used alternately (gather b reads buffer b % 2 while the packs of batch b + 1 fill the other one)
+    uint8_t* batch[2] = { nullptr, nullptr }; uint8_t* gathered[2] = { nullptr, nullptr }; double* dmax = nullptr;
+    hipEvent_t ev_free[2]; bool ev_valid[2] = { false, false };               // recorded behind the gather that last read buffer x
+    for (int x = 0; x < 2; ++x) {
+        if (rank == 0) { HIPOK(hipMalloc(&gathered[x], (size_t)world * G * fbytes)); batch[x] = gathered[x]; }      // rank 0 packs straight into its slice of the gathered batch
+        else HIPOK(hipMalloc(&batch[x], G * fbytes));
+        HIPOK(hipMemset(batch[x], 0, G * fbytes));
+        HIPOK(hipEventCreateWithFlags(&ev_free[x], hipEventDisableTiming));
+    }
+    HIPOK(hipMalloc(&dmax, sizeof(double) * (size_t)(2 * world + 2)));
+    HIPOK(hipMemset(dmax, 0, sizeof(double) * (size_t)(2 * world + 2)));
+    // comm-stream accounting: a pair of timing events around every gather of a sweep
+    const int max_gathers = (most + G - 1) / G + 1;
+    std::vector<hipEvent_t> g0(max_gathers), g1(max_gathers);
+    for (int i = 0; i < max_gathers; ++i) { HIPOK(hipEventCreate(&g0[i])); HIPOK(hipEventCreate(&g1[i])); }
+    int gathers_this_sweep = 0;
     std::vector<uint8_t> host_frames;                                       // verification sweep only, rank 0
     std::vector<uint32_t> frame_crc(a.frames, 0u);
     const bool pipelined = lanes >= 2;
@@ -179,13 +222,20 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         return 0;
     };
     auto gather = [&](int batch_no, bool verify) -> int {
+        const int x = batch_no & 1;
+        const int gi = gathers_this_sweep < max_gathers ? gathers_this_sweep : max_gathers - 1;
+        HIPOK(hipEventRecord(g0[gi], stream));
         NCCLOK(ncclGroupStart());
-        if (rank == 0) { for (int r = 1; r < world; ++r) NCCLOK(ncclRecv(gathered + (size_t)r * G * fbytes, G * fbytes, ncclUint8, r, comm, stream)); }
-        else NCCLOK(ncclSend(batch, G * fbytes, ncclUint8, 0, comm, stream));
+        if (rank == 0) { for (int r = 1; r < world; ++r) NCCLOK(ncclRecv(gathered[x] + (size_t)r * G * fbytes, G * fbytes, ncclUint8, r, comm, stream)); }
+        else NCCLOK(ncclSend(batch[x], G * fbytes, ncclUint8, 0, comm, stream));
         NCCLOK(ncclGroupEnd());
+        HIPOK(hipEventRecord(g1[gi], stream));
+        ++gathers_this_sweep;
+        HIPOK(hipEventRecord(ev_free[x], stream));                            // buffer x may be packed into again behind this
+        ev_valid[x] = true;
         if (verify && rank == 0) {
             host_frames.resize((size_t)world * G * fbytes);
-            HIPOK(hipMemcpyAsync(host_frames.data(), gathered, host_frames.size(), hipMemcpyDeviceToHost, stream));
+            HIPOK(hipMemcpyAsync(host_frames.data(), gathered[x], host_frames.size(), hipMemcpyDeviceToHost, stream));
             HIPOK(hipStreamSynchronize(stream));
             for (int r = 0; r < world; ++r)
                 for (int p = 0; p < G; ++p) {
@@ -202,8 +252,10 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     };
     auto sweep = [&](bool verify) -> int {
         int presented = 0;
+        gathers_this_sweep = 0;
         auto present = [&](int j, int frames_back) -> int {
-            if (j < (int)mine.size()) GSOK(gs4d_read_frame_rgba8_device(ctx, frames_back, batch + (size_t)(presented % G) * fbytes, fbytes));
+            const int x = (presented / G) & 1;
+            if (j < (int)mine.size()) GSOK(gs4d_read_frame_rgba8_device_after(ctx, frames_back, batch[x] + (size_t)(presented % G) * fbytes, fbytes, ev_valid[x] ? (void*)ev_free[x] : nullptr));
             ++presented;
             if (presented % G == 0 || presented == most) { if (gather((presented - 1) / G, verify)) return 1; }
             return 0;
@@ -217,9 +269,12 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         if (pipelined && present(most - 1, 0)) return 1;                    // the last frame of the sweep is presented inside the sweep
         return 0;
     };
+    double comm_tail_s = 0.0;
     auto fence = [&]() -> int {                                             // everything queued is done on every rank
         GSOK(gs4d_finish(ctx));
+        const auto tf = std::chrono::steady_clock::now();
         HIPOK(hipStreamSynchronize(stream));
+        comm_tail_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count();      // how long the comm stream ran on after the last frame was rendered
         NCCLOK(ncclAllReduce(dmax, dmax, 1, ncclDouble, ncclMax, comm, stream));
         HIPOK(hipStreamSynchronize(stream));
         return 0;
@@ -230,10 +285,13 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     for (int w = 0; w < a.warmup; ++w) { if (sweep(false)) return 1; }
     if (fence()) return 1;
     std::vector<double> secs;
+    double comm_busy_ms = 0.0, comm_tail_ms = 0.0;                          // of this rank, averaged over the timed sweeps
     for (int s = 0; s < a.sweeps; ++s) {
         const auto t0 = std::chrono::steady_clock::now();
         if (sweep(false) || fence()) return 1;
         double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int i = 0; i < gathers_this_sweep && i < max_gathers; ++i) { float ms = 0; if (hipEventElapsedTime(&ms, g0[i], g1[i]) == hipSuccess) comm_busy_ms += ms / a.sweeps; }
+        comm_tail_ms += comm_tail_s * 1e3 / a.sweeps;
         HIPOK(hipMemcpy(dmax, &el, sizeof el, hipMemcpyHostToDevice));     // maximum over ranks
         NCCLOK(ncclAllReduce(dmax, dmax, 1, ncclDouble, ncclMax, comm, stream));
         HIPOK(hipStreamSynchronize(stream));
@@ -241,6 +299,18 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         secs.push_back(el);
     }
     GSOK(gs4d_get_stats(ctx, st));
+    // every rank's comm accounting on rank 0 (two doubles per rank)
+    std::vector<double> comm_all((size_t)2 * world, 0.0);
+    {
+        const double mine2[2] = { comm_busy_ms, comm_tail_ms };
+        HIPOK(hipMemcpy(dmax + 2, mine2, sizeof mine2, hipMemcpyHostToDevice));
+        double* all = nullptr;
+        HIPOK(hipMalloc(&all, sizeof(double) * 2 * (size_t)world));
+        NCCLOK(ncclAllGather(dmax + 2, all, 2, ncclDouble, comm, stream));
+        HIPOK(hipStreamSynchronize(stream));
+        HIPOK(hipMemcpy(comm_all.data(), all, sizeof(double) * 2 * (size_t)world, hipMemcpyDeviceToHost));
+        (void)hipFree(all);
+    }
     if (rank == 0) {
         uint32_t crc = 0u;
         for (int k = 0; k < a.frames; ++k) crc = crc32_update(crc, (const uint8_t*)&frame_crc[k], 4);
@@ -248,23 +318,124 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         for (size_t i = 0; i < sorted.size(); ++i) for (size_t j = i + 1; j < sorted.size(); ++j) if (sorted[j] < sorted[i]) std::swap(sorted[i], sorted[j]);
         const double med = sorted.empty() ? 0.0 : sorted[sorted.size() / 2];
         printf("{\"program\": \"gs4d_sweep\", \"n_gpus\": %d, \"splats\": %zu, \"frames\": %d, \"width\": %d, \"height\": %d, \"frames_per_gather_per_rank\": %d, \"frame_lanes\": %d, "
-               "\"sweeps\": %d, \"ms_per_sweep\": %.4f, \"ms_per_frame\": %.5f, \"splats_per_s\": %.6g, \"frames_crc32\": \"%08x\", \"unordered_draws\": %llu, \"keygen_in_draw\": %llu}\n",
+               "\"sweeps\": %d, \"ms_per_sweep\": %.4f, \"ms_per_frame\": %.5f, \"splats_per_s\": %.6g, \"frames_crc32\": \"%08x\", \"unordered_draws\": %llu, \"keygen_in_draw\": %llu, "
+               "\"aborted_discarded\": %llu, \"batch_buffers\": 2, \"comm_stream_busy_ms_per_rank\": [",
                world, n, a.frames, a.width, a.height, G, lanes, a.sweeps, med * 1e3, med * 1e3 / a.frames, med > 0 ? (double)n * a.frames / med : 0.0,
-               a.verify ? crc : 0u, (unsigned long long)(st[7] & 0xFFFFFFFFu), (unsigned long long)(st[6] >> 32));
+               a.verify ? crc : 0u, (unsigned long long)(st[7] & 0xFFFFFFFFu), (unsigned long long)(st[6] >> 32), (unsigned long long)(st[2] >> 32));
+        for (int r = 0; r < world; ++r) printf("%s%.3f", r ? ", " : "", comm_all[2 * r]);
+        printf("], \"comm_stream_tail_ms_per_rank\": [");
+        for (int r = 0; r < world; ++r) printf("%s%.3f", r ? ", " : "", comm_all[2 * r + 1]);
+        printf("]}\n");
         fflush(stdout);
     }
     gs4d_destroy(ctx);
-    if (rank != 0) (void)hipFree(batch);
-    (void)hipFree(gathered); (void)hipFree(dmax);
+    for (int x = 0; x < 2; ++x) { if (rank != 0) (void)hipFree(batch[x]); (void)hipFree(gathered[x]); (void)hipEventDestroy(ev_free[x]); }
+    for (int i = 0; i < max_gathers; ++i) { (void)hipEventDestroy(g0[i]); (void)hipEventDestroy(g1[i]); }
+    (void)hipFree(dmax);
     (void)hipStreamDestroy(stream);
     ncclCommDestroy(comm);
     if (rank == 0) unlink(idfile.c_str());
     return 0;
 }
 
+// BASELINE.json configs[4]'s shape: ONE frame per step; splats cannot be sharded (the blend order is global), tiles can.  Every rank generates
+// the keys of and sorts ALL splats, builds the tile lists of and composites only the rows of 8x8 tiles ty % world == rank
+// (gs4d_set_tile_shard), packs its rows (gs4d_read_band_rgba8_device) and sends the band to rank 0, which holds the image as `world`
+// bands.  --frames is the number of steps per timed window here; the frame is rendered at t = t_max / 2.
+int sweep_tiles(const Args& a, int rank, int world, gs4d_ctx* ctx, ncclComm_t comm, hipStream_t stream, gs4d_buf data, const std::vector<gs4d_buf>& keys, const std::vector<gs4d_buf>& idx, int lanes, const float cam_pos[3]) {
+    const size_t n = a.splats;
+    GSOK(gs4d_set_tile_shard(ctx, rank, world));
+    const int tiles_y = (a.height + 7) / 8;
+    std::vector<size_t> band_bytes(world, 0), band_off(world + 1, 0);
+    for (int ty = 0; ty < tiles_y; ++ty) band_bytes[ty % world] += (size_t)std::min(8, a.height - ty * 8) * a.width * 4;
+    for (int r = 0; r < world; ++r) band_off[r + 1] = band_off[r] + band_bytes[r];
+    int rows = 0;
+    GSOK(gs4d_band_rows(ctx, &rows));
+    if ((size_t)rows * a.width * 4 != band_bytes[rank]) { fprintf(stderr, "[rank %d] band size mismatch\n", rank); return 1; }
+    uint8_t* band[2] = { nullptr, nullptr }; uint8_t* image[2] = { nullptr, nullptr }; double* dmax = nullptr;
+    for (int x = 0; x < 2; ++x) {
+        if (rank == 0) { HIPOK(hipMalloc(&image[x], band_off[world])); band[x] = image[x]; }
+        else HIPOK(hipMalloc(&band[x], std::max<size_t>(band_bytes[rank], 4)));
+    }
+    HIPOK(hipMalloc(&dmax, sizeof(double)));
+    const float t = a.t_max * 0.5f;
+    GSOK(gs4d_set_uniform_1f(ctx, GS4D_U_TIME, t));
+    uint64_t step_no = 0;
+    auto step = [&]() -> int {
+        const int b = (int)(step_no % (uint64_t)lanes), x = (int)(step_no & 1u);
+        ++step_no;
+        GSOK(gs4d_clear(ctx));
+        GSOK(gs4d_keygen(ctx, data, t, cam_pos, keys[b], idx[b], n, GS4D_KEY_REF_INV_EUCLID));
+        GSOK(gs4d_sort_pairs(ctx, keys[b], idx[b], n));
+        GSOK(gs4d_bind_storage(ctx, 1, idx[b]));
+        GSOK(gs4d_draw_instanced(ctx, n));
+        if (band_bytes[rank]) GSOK(gs4d_read_band_rgba8_device(ctx, band[x], band_bytes[rank]));
+        NCCLOK(ncclGroupStart());
+        if (rank == 0) { for (int r = 1; r < world; ++r) if (band_bytes[r]) NCCLOK(ncclRecv(image[x] + band_off[r], band_bytes[r], ncclUint8, r, comm, stream)); }
+        else if (band_bytes[rank]) NCCLOK(ncclSend(band[x], band_bytes[rank], ncclUint8, 0, comm, stream));
+        NCCLOK(ncclGroupEnd());
+        return 0;
+    };
+    auto fence = [&]() -> int {
+        GSOK(gs4d_finish(ctx));
+        HIPOK(hipStreamSynchronize(stream));
+        HIPOK(hipMemset(dmax, 0, sizeof(double)));
+        NCCLOK(ncclAllReduce(dmax, dmax, 1, ncclDouble, ncclMax, comm, stream));
+        HIPOK(hipStreamSynchronize(stream));
+        return 0;
+    };
+    uint32_t crc = 0u;
+    if (a.verify) {
+        if (step() || fence()) return 1;
+        if (rank == 0) {
+            // bands -> image rows: tile row ty lives in rank ty % world's band, the rank's tile rows in ascending ty
+            std::vector<uint8_t> bands(band_off[world]), img((size_t)a.width * a.height * 4);
+            HIPOK(hipMemcpy(bands.data(), image[(step_no - 1) & 1u], bands.size(), hipMemcpyDeviceToHost));
+            std::vector<size_t> cur(band_off.begin(), band_off.end() - 1);
+            for (int ty = 0; ty < tiles_y; ++ty) {
+                const size_t bytes = (size_t)std::min(8, a.height - ty * 8) * a.width * 4;
+                memcpy(img.data() + (size_t)ty * 8 * a.width * 4, bands.data() + cur[ty % world], bytes);
+                cur[ty % world] += bytes;
+            }
+            crc = crc32_update(0u, img.data(), img.size());
+            if (!a.dump.empty()) { mkdir(a.dump.c_str(), 0755); if (!write_file(a.dump + "/frame_tiles.rgba8", img.data(), img.size())) return 1; }
+        }
+    }
+    for (int w = 0; w < a.warmup * 4; ++w) { if (step()) return 1; }
+    if (fence()) return 1;
+    std::vector<double> secs;
+    for (int s = 0; s < a.sweeps; ++s) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < a.frames; ++k) { if (step()) return 1; }
+        if (fence()) return 1;
+        double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        HIPOK(hipMemcpy(dmax, &el, sizeof el, hipMemcpyHostToDevice));
+        NCCLOK(ncclAllReduce(dmax, dmax, 1, ncclDouble, ncclMax, comm, stream));
+        HIPOK(hipStreamSynchronize(stream));
+        HIPOK(hipMemcpy(&el, dmax, sizeof el, hipMemcpyDeviceToHost));
+        secs.push_back(el);
+    }
+    uint64_t st[8];
+    GSOK(gs4d_get_stats(ctx, st));
+    if (rank == 0) {
+        std::vector<double> sorted = secs;
+        for (size_t i = 0; i < sorted.size(); ++i) for (size_t j = i + 1; j < sorted.size(); ++j) if (sorted[j] < sorted[i]) std::swap(sorted[i], sorted[j]);
+        const double med = sorted.empty() ? 0.0 : sorted[sorted.size() / 2];
+        printf("{\"program\": \"gs4d_sweep\", \"mode\": \"shard_tiles\", \"n_gpus\": %d, \"splats\": %zu, \"steps_per_window\": %d, \"width\": %d, \"height\": %d, \"frame_lanes\": %d, "
+               "\"windows\": %d, \"ms_per_frame\": %.5f, \"splats_per_s\": %.6g, \"image_crc32\": \"%08x\", \"tile_list_entries_rank0\": %llu, \"unordered_draws\": %llu}\n",
+               world, n, a.frames, a.width, a.height, lanes, a.sweeps, med * 1e3 / a.frames, med > 0 ? (double)n * a.frames / med : 0.0, crc,
+               (unsigned long long)st[0], (unsigned long long)(st[7] & 0xFFFFFFFFu));
+        fflush(stdout);
+    }
+    for (int x = 0; x < 2; ++x) { if (rank != 0) (void)hipFree(band[x]); (void)hipFree(image[x]); }
+    (void)hipFree(dmax);
+    return 0;
+}
+
 } // namespace
 
 int main(int argc, char** argv) {
+    g_started = (long)time(nullptr);
     Args a;
     for (int i = 1; i < argc; ++i) {
         const std::string k = argv[i];
@@ -281,24 +452,32 @@ int main(int argc, char** argv) {
         else if (k == "--png") a.png = val();
         else if (k == "--png-every") a.png_every = atoi(val());
         else if (k == "--no-verify") a.verify = false;
-        else { fprintf(stderr, "usage: gs4d_sweep [--gpus N] [--splats n] [--frames 256] [--gather-every 8] [--sweeps 3] [--warmup 1] [--width W --height H] [--dump dir] [--png prefix [--png-every 32]] [--no-verify]\n"); return 2; }
+        else if (k == "--shard-tiles") a.shard_tiles = true;
+        else { fprintf(stderr, "usage: gs4d_sweep [--gpus N] [--splats n] [--frames 256] [--gather-every 8] [--sweeps 3] [--warmup 1] [--width W --height H] [--dump dir] [--png prefix [--png-every 32]] [--no-verify] [--shard-tiles]\n"); return 2; }
     }
     if (a.gpus < 1 || a.frames < 1 || a.splats < 1 || a.png_every < 1) { fprintf(stderr, "bad arguments\n"); return 2; }
     const char* er = getenv("RANK"); const char* ew = getenv("WORLD_SIZE");
     if (er && ew) {                                                         // one rank of a job somebody else launched
         const int rank = atoi(er), world = atoi(ew), local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
-        const std::string idfile = std::string("/tmp/gs4d_sweep_") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") + ".id";
-        return run_rank(a, rank, world, local, idfile);
+        const std::string port = getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0";
+        const std::string idfile = std::string("/tmp/gs4d_sweep_") + port + ".id";
+        // the job's nonce: the launcher's run id where it sets one (torchrun: TORCHELASTIC_RUN_ID; GS4D_SWEEP_JOB to name it yourself); without
+        // one a rank accepts only a file written after it started itself (rank 0 deletes a leftover before it writes)
+        std::string nonce;
+        if (const char* j = getenv("GS4D_SWEEP_JOB")) nonce = j;
+        else if (const char* j2 = getenv("TORCHELASTIC_RUN_ID")) nonce = j2;
+        return run_rank(a, rank, world, local, idfile, nonce);
     }
     const std::string idfile = "/tmp/gs4d_sweep_" + std::to_string((long)getpid()) + ".id";
     unlink(idfile.c_str());
-    if (a.gpus == 1) return run_rank(a, 0, 1, 0, idfile);
+    const std::string nonce = "pid" + std::to_string((long)getpid());
+    if (a.gpus == 1) return run_rank(a, 0, 1, 0, idfile, nonce);
     // one process per GPU, forked here — before this process has made a single HIP call
     std::vector<pid_t> kids;
     for (int r = 0; r < a.gpus; ++r) {
         const pid_t p = fork();
         if (p < 0) { perror("fork"); return 1; }
-        if (p == 0) _exit(run_rank(a, r, a.gpus, r, idfile));
+        if (p == 0) _exit(run_rank(a, r, a.gpus, r, idfile, nonce));
         kids.push_back(p);
     }
     int rc = 0;

@@ -10,8 +10,10 @@ exactly the call sequence of the reference's Scene::Render with sorting on (Scen
           with a single frame lane (nothing overlaps: "latency_ms_one_lane").
   N > 1   workload = BASELINE.json configs[3], exactly: 1,000,000 4D splats, the 256-frame time sweep t_k = 50 k / 255, frame k on rank
           k mod N (one process per GPU, no data-path collective); the finished frames travel to rank 0 in the presentation format
-          (RGBA8) with one RCCL gather per --gather-every frames of every rank.  A step is one whole sweep (256 frames), so the total
-          work per step is fixed as N grows: "scaling": "strong".
+          (RGBA8) with one RCCL gather per --gather-every frames of every rank, from two batch buffers used alternately (a pack never waits
+          for the gather that is in flight).  A step is one whole sweep (256 frames), so the total work per step is fixed as N grows:
+          "scaling": "strong".  The line carries, per rank, how long the comm stream was busy per sweep and how long it ran on after the
+          rank's last frame (so that a scaling curve explains itself).
 
 Timing: W untimed warm-up steps, then windows of EXACTLY K steps, each bracketed by barrier + synchronize on both sides, maximum over
 ranks per window; `ms_per_step` / `value` are the MEDIAN window (all windows are listed: a 20-step window lasts 3 ms at N = 1, short
@@ -34,7 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6.3 TB/s
 SWEEP_FRAMES = 256          # BASELINE.json configs[3]
-PROFILE_TAG = "r02"         # profiles/<tag>_pmc_traffic_c{2,3}.json hold the per-launch HBM traffic of this build's kernels
+PROFILE_TAG = "r03"         # profiles/<tag>_pmc_traffic_c{2,3}.json hold the per-launch HBM traffic of this build's kernels
 
 # stage -> (kernel the stage is made of, launches per frame); "sort" and "pairsort" launch counts come from the library's stats
 KERNELS = {"keygen": "gs4d::k_keygen", "sort": "gs4d::k_os_pass", "preprocess": "gs4d::k_project_count", "binning": "gs4d::k_bucket_scatter",
@@ -188,7 +190,13 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
     cred = [k for k, v in warm_ms.items() if v > 0 and alg[k] > 0]
     dominant = max(cred, key=lambda k: warm_ms[k]) if cred else None
     ctx.set_profiling([dominant] if (dominant and stage_events) else False, every=8)
+    aborted_before = ctx.stats()["aborted_discarded"]
     secs = timed_windows(lambda k: sc.frame(), fence, steps, 0, windows)
+    # frames that aborted on the device (tile-list capacity, list length) and were cleared away before anything observed them are never
+    # re-run: a timed window that contains one has timed an incomplete render.  The library counts them; the bench refuses such a window.
+    aborted = ctx.stats()["aborted_discarded"] - aborted_before
+    if aborted:
+        raise RuntimeError(f"{aborted} timed frame(s) aborted on the device and were never completed: the measurement is invalid")
     stage_ms = ctx.timings()
     ctx.set_profiling(False)
     steady_ms = None
@@ -205,7 +213,7 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
     sc.close()
     ms = sorted(1e3 * s / steps for s in secs)
     med = ms[len(ms) // 2]
-    res = {"ms_per_step": med, "value": n / (med * 1e-3), "windows_ms_per_step": [round(1e3 * s / steps, 5) for s in secs],
+    res = {"ms_per_step": med, "value": n / (med * 1e-3), "windows_ms_per_step": [round(1e3 * s / steps, 5) for s in secs], "aborted_in_timed_windows": aborted,
            "stats": stats, "warm_ms": warm_ms, "stage_ms": stage_ms, "steady_ms": steady_ms}
     return res, rec, (cam, view, proj)
 
@@ -266,11 +274,19 @@ def single_gpu(args, gs4d, scenes, device):
         c3 = {"workload": "10,000,000 random 3D splats in a 400^3 cube, single 1080p frame (BASELINE.json configs[2])", "splats": n3,
               "ms_per_step": r3["ms_per_step"], "value": r3["value"], "unit": "splats/s", "windows_ms_per_step": r3["windows_ms_per_step"],
               "tile_list_entries": r3["stats"]["entries"], "longest_tile_list": r3["stats"]["longest_list"], "unordered_draws": r3["stats"]["unordered_draws"],
+              "aborted_frames_in_timed_windows": r3["aborted_in_timed_windows"],
               "roofline": roofline_block(r3["stats"], r3["stage_ms"], r3["warm_ms"], n3, r3["ms_per_step"], os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_c3.json"))}
         if not args.no_latency:
             one3, _, _ = measure_single(gs4d, scenes, n3, 10, 5, 3, device, stage_events=False, lanes=1, steady_stages=8)
             c3["latency_ms_one_lane"] = round(one3["ms_per_step"], 5)
             alone_block(c3["roofline"], one3, n3)
+    one_pair = None
+    if not args.no_latency:
+        # the reference's own buffer layout: ONE key / index pair for every frame (Scenes.h m_key_buf / m_values_buf).  Frame f + 1 writes the
+        # buffers frame f's sort is still filling: the lanes order themselves on the device (events), consecutive frames overlap less.
+        r1, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=args.lanes, keybufs=1)
+        one_pair = {"ms_per_step": round(r1["ms_per_step"], 5), "value": r1["value"], "unit": "splats/s",
+                    "note": "same workload with one key / sort-index buffer pair instead of one per frame lane: the write-after-write dependency between consecutive frames' sorts serialises part of every frame"}
     cpu = None if args.no_cpu_baseline else cpu_baseline(rec, cam, view, proj)
     st = res["stats"]
     return {
@@ -283,7 +299,9 @@ def single_gpu(args, gs4d, scenes, device):
         "latency_ms_one_lane": latency,
         "config": {"workload": f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else ""),
                    "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": 1, "frame_lanes": st["lanes"],
-                   "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "overflow_reruns": st["reruns"]},
+                   "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "overflow_reruns": st["reruns"],
+                   "aborted_frames_in_timed_windows": res["aborted_in_timed_windows"], "key_index_buffer_pairs": kb},
+        "one_key_index_pair": one_pair,
         "roofline": roofline,
         "c3": c3,
         "cpu_baseline": cpu,
@@ -316,9 +334,14 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
     G = max(1, args.gather_every)
     mine = sharding.frames_for_rank(SWEEP_FRAMES, rank, world)            # frame k -> rank k mod world
     most = len(sharding.frames_for_rank(SWEEP_FRAMES, 0, world))          # ranks with fewer frames pad their last batch
-    batch = torch.zeros((G, H * W), dtype=torch.int32, device="cuda")
-    gathered = [torch.empty((G, H * W), dtype=torch.int32, device=gdev) for _ in range(world)] if rank == 0 else None
+    # two batch buffers, used alternately: the packs of batch b + 1 fill one while the gather of batch b still reads the other.  A pack waits
+    # only for the event recorded behind the gather that last read ITS buffer (gs4d_read_frame_rgba8_device_after), not for the comm stream.
+    batch = [torch.zeros((G, H * W), dtype=torch.int32, device="cuda") for _ in range(2)]
+    gathered = [[torch.empty((G, H * W), dtype=torch.int32, device=gdev) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+    free_ev = [torch.cuda.Event(), torch.cuda.Event()]
+    free_valid = [False, False]
     pipelined = ctx.stats()["lanes"] >= 2                                 # with one frame lane there is no previous image to read
+    comm = {"busy_ms": 0.0, "tail_ms": 0.0, "pairs": []}
 
     def sweep(_k):
         """One step: this rank's frames of the 256-frame sweep.  Presentation is software-pipelined as a swap chain is — frame j is queued
@@ -328,11 +351,18 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
         state = {"p": 0}
 
         def present(j, frames_back):
+            x = (state["p"] // G) & 1
             if j < len(mine):
-                ctx.read_frame_rgba8_device(frames_back, batch[state["p"] % G].data_ptr(), H * W * 4)
+                ctx.read_frame_rgba8_device_after(frames_back, batch[x][state["p"] % G].data_ptr(), H * W * 4, free_ev[x].cuda_event if free_valid[x] else None)
             state["p"] += 1
             if state["p"] % G == 0 or state["p"] == most:
-                sharding.gather_frames(dist, batch if backend == "nccl" else batch.cpu(), gathered, dst=0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(comm_stream)
+                sharding.gather_frames(dist, batch[x] if backend == "nccl" else batch[x].cpu(), gathered[x], dst=0)
+                e1.record(comm_stream)
+                free_ev[x].record(comm_stream)
+                free_valid[x] = True
+                comm["pairs"].append((e0, e1))
 
         for j in range(most):
             rendered = j < len(mine)
@@ -351,11 +381,11 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
         for k in range(SWEEP_FRAMES):
             sc.frame(sharding.sweep_time(k, SWEEP_FRAMES))
             if pipelined and k >= 1:
-                ctx.read_frame_rgba8_device(1, batch[(k - 1) % G].data_ptr(), H * W * 4)
+                ctx.read_frame_rgba8_device_after(1, batch[0][(k - 1) % G].data_ptr(), H * W * 4)
             elif not pipelined:
-                ctx.read_frame_rgba8_device(0, batch[k % G].data_ptr(), H * W * 4)
+                ctx.read_frame_rgba8_device_after(0, batch[0][k % G].data_ptr(), H * W * 4)
         if pipelined:
-            ctx.read_frame_rgba8_device(0, batch[(SWEEP_FRAMES - 1) % G].data_ptr(), H * W * 4)
+            ctx.read_frame_rgba8_device_after(0, batch[0][(SWEEP_FRAMES - 1) % G].data_ptr(), H * W * 4)
 
     def fence_local():
         ctx.finish()
@@ -370,7 +400,11 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
 
     def fence():
         ctx.finish()
+        t0 = time.perf_counter()
         torch.cuda.synchronize()
+        comm["tail_ms"] += 1e3 * (time.perf_counter() - t0)     # how long the comm stream ran on after this rank's last frame was rendered
+        comm["busy_ms"] += sum(a.elapsed_time(b) for a, b in comm["pairs"])
+        comm["pairs"].clear()
         dist.barrier()
         torch.cuda.synchronize()
 
@@ -379,7 +413,17 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
-    secs = timed_windows(sweep, fence, args.steps, args.warmup, args.windows, reduce_max)
+    def timed():
+        for k in range(args.warmup):
+            sweep(k)
+        fence()
+        comm["busy_ms"] = comm["tail_ms"] = 0.0
+        return timed_windows(sweep, fence, args.steps, 0, args.windows, reduce_max)
+    secs = timed()
+    nsweeps = max(1, args.steps * args.windows)
+    mine_comm = torch.tensor([comm["busy_ms"] / nsweeps, comm["tail_ms"] / max(1, args.windows)], dtype=torch.float64, device=gdev)
+    all_comm = [torch.zeros(2, dtype=torch.float64, device=gdev) for _ in range(world)]
+    dist.all_gather(all_comm, mine_comm)
     stats = ctx.stats()
     sc.close()
     dist.destroy_process_group()
@@ -396,7 +440,10 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
         "windows_ms_per_step": [round(1e3 * s / args.steps, 4) for s in secs],
         "config": {"workload": "1,000,000 4D splats, 256-frame time sweep t_k = 50 k / 255, frame k on rank k mod N, RGBA8 frames gathered on rank 0 (BASELINE.json configs[3])",
                    "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": SWEEP_FRAMES, "ms_per_frame": med / SWEEP_FRAMES,
-                   "frames_per_gather_per_rank": G, "frame_lanes": stats["lanes"], "tile_list_entries": stats["entries"], "overflow_reruns": stats["reruns"]},
+                   "frames_per_gather_per_rank": G, "batch_buffers": 2, "frame_lanes": stats["lanes"], "tile_list_entries": stats["entries"], "overflow_reruns": stats["reruns"],
+                   "aborted_frames": stats["aborted_discarded"]},
+        "comm": {"stream_busy_ms_per_sweep_per_rank": [round(float(t[0]), 3) for t in all_comm], "stream_tail_ms_per_window_per_rank": [round(float(t[1]), 3) for t in all_comm],
+                 "note": "busy: sum of the gathers' durations on the comm stream (for a sender that includes waiting for rank 0's matching receive); tail: time the comm stream ran on after the rank's last frame was rendered (exposed)"},
         "roofline": {"bound": "hbm", "kernel": None, "achieved": round(frame_ach, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(frame_ach / (HBM_PEAK_GBS * world), 5),
                      "traffic": None, "note": "whole-job algorithmic bytes over all ranks against N x 8 TB/s; the per-kernel figure is in the N = 1 line"},
         "one_gpu_same_workload": one_gpu,

@@ -136,6 +136,11 @@ GS4D_API int gs4d_read_pixels_rgba8_device(gs4d_ctx* ctx, void* dptr, size_t byt
  * (clear, keygen, sort, draw) never waits for frame f: its host thread stays ahead of the device.  GS4D_E_INVALID when there is no such
  * image (frames_back > 1, one frame lane, or no gs4d_clear yet). */
 GS4D_API int gs4d_read_frame_rgba8_device(gs4d_ctx* ctx, int frames_back, void* dptr, size_t bytes);
+/* The same, for callers that cycle through several destination buffers (a double-buffered gather batch): the pack does NOT wait for
+ * everything queued on the caller's stream — which would include the transfer still reading the OTHER buffer — but only for `hip_event`
+ * (a hipEvent_t passed as void*, recorded by the caller behind the last work that used `dptr`; NULL: `dptr` is free, wait for nothing).
+ * As with the call above, work the caller queues on its stream afterwards sees the pixels. */
+GS4D_API int gs4d_read_frame_rgba8_device_after(gs4d_ctx* ctx, int frames_back, void* dptr, size_t bytes, void* hip_event);
 /* Name the caller's HIP stream (hipStream_t passed as void*; NULL: none — note that the legacy default stream's handle IS NULL: give a
  * stream of your own).  The library keeps running on its own streams, but from now on
  *  (a) a buffer the caller rewrites on that stream (gs4d_buffer_device_ptr + gs4d_buffer_invalidate, in that call order, THEN the
@@ -163,7 +168,7 @@ GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);           
 /* Start and end of every timed stage of the frames recorded so far (at most 128), in ms since the first timed stage of frame 0:
  * ms[frame][stage][2].  Shows how consecutive frames overlap.  Blocking; does not restart the ring (gs4d_get_timings does). */
 GS4D_API int gs4d_get_timeline(gs4d_ctx* ctx, float* ms, int max_frames, int* frames);
-GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[8]);                    /* [0] tile-list entries of the last draw, [1] capacity, [2] re-runs after overflow, [3] tiles,
+GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[8]);                    /* [0] tile-list entries of the last draw, [1] capacity, [2] low 32 bits: re-runs after overflow, high 32 bits: draws that aborted on the device and were cleared away unobserved (never re-run; a frame loop without read-backs checks this stays 0), [3] tiles,
                                                                                       [4] radix passes launched by the last gs4d_sort_pairs, [5] by the last draw's tile sort (0: the draw built unordered tile lists),
                                                                                       [6] low 32 bits: frame lanes, high 32 bits: draws that generated the depth keys of the preceding gs4d_keygen themselves (see gs4d_keygen), [7] low 32 bits: draws so far on the unordered tile-list path, high 32 bits: longest tile list of the last such draw */
 /* Projected records of the last draw, 16 floats per record in record order:

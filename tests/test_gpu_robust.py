@@ -1,0 +1,222 @@
+"""GPU: what happens when something goes wrong, or late — contract violations, draws that are validated after the fact, draws that are
+never observed.  Through the C ABI, against the CPU checker (image L-infinity <= 1e-4).
+
+* a key buffer rewritten under a queued sort without gs4d_buffer_invalidate: GS4D_E_DEVICE, not a memory fault (sort.hip's scatter is bounded);
+* a draw whose tile lists overflow is re-run when somebody looks at the image — also when the context has moved on to another frame lane;
+* a draw whose unordered lists cannot be ordered in the compositor is re-run on the ordered path WITHOUT the caller's sort index, which
+  the application (one key / index pair, the reference's layout: Scenes.h m_key_buf / m_values_buf) has meanwhile overwritten;
+* frames that abort on the device and are cleared away unobserved are counted (gs4d_get_stats) and still teach the context its capacities;
+* glClearColor between a draw and its re-run does not repaint the earlier frame.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_render import cam_mats, linf, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipDeviceSynchronize.restype = C.c_int
+    return hip
+
+
+def test_key_buffer_rewritten_under_a_queued_sort_is_an_error_not_a_fault(gs4d, monkeypatch):
+    """The caller keeps a device pointer to its key buffer, lets gs4d_keygen fill it (the kernel also accumulates the digit histograms the
+    sort will use), overwrites the keys through the pointer WITHOUT gs4d_buffer_invalidate and then sorts: histograms and keys no longer
+    describe the same array.  The sort must stay inside its buffers and the context must report the frame as failed."""
+    monkeypatch.setenv("GS4D_FUSE_KEYGEN", "0")              # key generation is launched at once (not folded into a later draw)
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    n, W, H = 300000, 640, 360
+    ctx = gs4d.Context(W, H)
+    pos, q, sc, rgba = scenes.cube_params(n, seed=91)
+    rec = gs4d.build_records_3d(pos, q, sc, rgba)
+    cam = scenes.CAM_CUBE
+    data, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    kptr, nbytes = ctx.device_ptr(kb)                         # taken BEFORE the keys are generated; never announced again
+    assert nbytes == 4 * n
+    ctx.keygen(data, 0.0, cam[0], kb, ib, n)
+    hip = _hip()
+    assert hip.hipDeviceSynchronize() == 0
+    junk = np.random.default_rng(5).integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)     # digits unlike the real keys' in every byte
+    assert hip.hipMemcpy(C.c_void_p(kptr), junk.ctypes.data_as(C.c_void_p), 4 * n, 1) == 0
+    ctx.sort_pairs(kb, ib, n)                                 # uses the histograms of the keys that are no longer there
+    with pytest.raises(gs4d.Gs4dError, match="device-side check failed"):
+        ctx.finish()
+    ctx.close()
+    # the device is fine: a fresh context renders
+    ctx = gs4d.Context(W, H)
+    ctx.clear()
+    assert ctx.read_pixels().shape == (H, W, 4)
+    ctx.close()
+
+
+def _big_splats(gs4d, n=300, seed=11):
+    pos, q, scale, rgba = scenes.cube_params(n, seed=seed)
+    rgba[:, 3] *= 0.35
+    return gs4d.build_records_3d(pos * 0.02, q, scale * 8.0, rgba)       # close-up: each covers thousands of tiles
+
+
+@pytest.mark.parametrize("path", ["auto", "ordered"])
+def test_overflow_rerun_seen_from_another_lane(gs4d, oracle, monkeypatch, path):
+    """First frame of a context: the tile lists outgrow their speculative capacity.  Before anybody looks at the image the application
+    queues the next frame's key generation — the context moves to the next lane.  read_pixels then re-runs the draw on ITS lane and
+    must read the pixels behind that re-run, not behind the lane's old tail event."""
+    if path == "ordered":
+        monkeypatch.setenv("GS4D_DRAW_PATH", "ordered")
+    else:
+        monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    W, H = 1001, 701
+    cam = ((0.0, 0.0, 30.0), (0.0, 0.0, -1.0))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    rec = _big_splats(gs4d)
+    n = rec.shape[0]
+    ctx = gs4d.Context(W, H)
+    assert ctx.stats()["lanes"] >= 2
+    data = ctx.buffer(rec)
+    a = (ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n))
+    b = (ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n))
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.bind(2, data)
+    ctx.clear()
+    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+    ctx.keygen(data, 0.0, cam[0], *a, n)
+    ctx.sort_pairs(*a, n)
+    ctx.bind(1, a[1])
+    ctx.draw_instanced(n)
+    ctx.keygen(data, 0.0, cam[0], *b, n)                       # the next frame starts: another lane is current from here on
+    ctx.sort_pairs(*b, n)
+    img = ctx.read_pixels()                                    # still the first image: validated, re-run, read
+    eimg, _, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    st = ctx.stats()
+    assert st["reruns"] >= 1 and st["entries"] > 2 * n + 65536
+    assert linf(img, eimg) <= TOL
+    ctx.close()
+
+
+def test_fallback_rerun_does_not_need_the_callers_sort_index(gs4d, oracle, monkeypatch):
+    """ONE key / index buffer pair (the reference's layout).  Frame A: thousands of splats on one spot with ONE depth key — no depth slab
+    separates them, the unordered draw aborts and has to be re-run on the instance-ordered path.  Before anybody observes it the
+    application generates and sorts frame B's keys INTO THE SAME BUFFERS and draws B on top (no clear).  A's re-run must blend in A's
+    order, not in whatever the index buffer holds by then."""
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    W, H = 256, 256
+    cam = ((0.0, 0.0, 60.0), (0.0, 0.0, -1.0))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    n = 3000
+    pos, q, sc, rgba = scenes.cube_params(n, seed=3050)
+    rgba[:, 3] *= 0.05
+    pos[:, 0:2] = 0.0
+    recA = gs4d.build_records_3d(pos * 0.0, q, sc * 1.5, rgba)              # one depth: equal keys, blend order = record order
+    pos4, q4, sc4, life, fade, vel, rgba4 = scenes.cube_params_4d(n, seed=77)
+    rgba4[:, 3] *= 0.3
+    recB = gs4d.build_records_4d(pos4 * 0.1, q4, sc4 * 2.0, life, fade, vel, rgba4)
+    ctx = gs4d.Context(W, H)
+    dA, dB, kb, ib = ctx.buffer(recA), ctx.buffer(recB), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.clear()
+    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+    ctx.bind(1, ib)
+    ctx.bind(2, dA)
+    ctx.keygen(dA, 0.0, cam[0], kb, ib, n)
+    ctx.sort_pairs(kb, ib, n)
+    ctx.draw_instanced(n)
+    tB = 2.0
+    ctx.set_uniforms(time=tB)
+    ctx.bind(2, dB)
+    ctx.keygen(dB, tB, cam[0], kb, ib, n)                      # same buffers: frame A's order is gone from them
+    ctx.sort_pairs(kb, ib, n)
+    ctx.draw_instanced(n)                                     # blends onto A's pixels (no clear in between)
+    img = ctx.read_pixels()
+    eimg = oracle.clear_image(W, H)
+    for rec, t in ((recA, 0.0), (recB, tB)):
+        _, ekeys = oracle.keygen(rec, t, cam[0])
+        _, eperm = oracle.sort_pairs(ekeys.view(np.uint32), np.arange(n, dtype=np.uint32), "lsd")
+        oracle.composite(oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t=t), eperm, oracle.MODE_4D, W, H, eimg)
+    st = ctx.stats()
+    assert st["reruns"] >= 1
+    assert linf(img, eimg) <= TOL
+    perm = ctx.read(ib, np.uint32, n)                         # and the caller's buffers hold frame B's order
+    assert np.array_equal(perm, eperm)
+    ctx.close()
+
+
+def test_aborted_frames_nobody_looked_at_are_counted_and_learned_from(gs4d, oracle, monkeypatch):
+    """A frame loop without read-backs (bench.py's timed window): Clear -> keygen -> sort -> Draw, again and again.  The first frames of
+    this scene overflow the speculative tile-list capacity and are cleared away before anybody sees them: they are not re-run, but they
+    are counted, and the capacity they asked for is there for the later frames — which then run complete."""
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    W, H = 1001, 701
+    cam = ((0.0, 0.0, 30.0), (0.0, 0.0, -1.0))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    rec = _big_splats(gs4d, seed=12)
+    n = rec.shape[0]
+    ctx = gs4d.Context(W, H)
+    lanes = ctx.stats()["lanes"]
+    data = ctx.buffer(rec)
+    pairs = [(ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)) for _ in range(lanes)]
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.bind(2, data)
+    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+
+    def frame(f):
+        kb, ib = pairs[f % lanes]
+        ctx.clear()
+        ctx.keygen(data, 0.0, cam[0], kb, ib, n)
+        ctx.sort_pairs(kb, ib, n)
+        ctx.bind(1, ib)
+        ctx.draw_instanced(n)
+    for f in range(3 * lanes):
+        frame(f)
+    ctx.finish()
+    st = ctx.stats()
+    assert st["aborted_discarded"] >= 1                       # the first round of lanes ran with too little capacity
+    settled = st["aborted_discarded"]
+    for f in range(3 * lanes, 5 * lanes):
+        frame(f)
+    ctx.finish()
+    st2 = ctx.stats()
+    assert st2["aborted_discarded"] == settled                # nothing aborts any more: every later frame was a complete render
+    eimg, _, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    assert linf(ctx.read_pixels(), eimg) <= TOL
+    assert ctx.stats()["reruns"] == st2["reruns"]             # the frame that was read needed no re-run either
+    ctx.close()
+
+
+def test_clear_colour_set_after_a_draw_does_not_repaint_its_rerun(gs4d, oracle, monkeypatch):
+    """glClearColor only affects later glClear calls.  A draw onto a (lazily) cleared image whose tile lists overflow is re-run after the
+    application has already set the next frame's clear colour: the re-run composites over the colour the image was cleared with."""
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    W, H = 1001, 701
+    cam = ((0.0, 0.0, 30.0), (0.0, 0.0, -1.0))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    rec = _big_splats(gs4d, seed=13)
+    n = rec.shape[0]
+    ctx = gs4d.Context(W, H)
+    data, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.clear()
+    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+    ctx.keygen(data, 0.0, cam[0], kb, ib, n)
+    ctx.sort_pairs(kb, ib, n)
+    ctx.bind(1, ib)
+    ctx.bind(2, data)
+    ctx.draw_instanced(n)                                     # overflows: pending validation
+    ctx.set_clear_color((1.0, 0.0, 1.0, 1.0))                 # for the NEXT clear
+    img = ctx.read_pixels()
+    assert ctx.stats()["reruns"] >= 1
+    eimg, _, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    assert linf(img, eimg) <= TOL
+    ctx.clear()
+    assert np.array_equal(ctx.read_pixels()[0, 0], np.array([1.0, 0.0, 1.0, 1.0], np.float32))
+    ctx.close()
