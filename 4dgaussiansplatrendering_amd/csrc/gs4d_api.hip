@@ -34,6 +34,7 @@ struct Buffer {
     size_t bytes = 0;
     uint64_t version = 0;          // bumped by every write; the SoA shadow and the keygen-histogram hand-off compare against it
     float4* soa = nullptr;         // lazily built SoA shadow of 96-B SplatData records
+    bool soa_compact = false;      // ... in the 72-byte layout of a symmetric sig (preprocess.hip)
     size_t soa_n = 0;
     uint64_t soa_version = ~0ull;
     uint32_t* bbox_dev = nullptr;  // 16 words: bounding box of pos / mu_t / velocity, reduced by the repack kernel
@@ -273,11 +274,17 @@ int ensure_soa(gs4d_ctx* c, Buffer& b) {
     // bounding box of everything the sort key depends on (upload-time work: one small read-back per refresh)
     uint32_t init[16]; for (int i = 0; i < 16; ++i) init[i] = i < 7 ? 0xFFFFFFFFu : 0u;
     if (!b.bbox_dev) HIPCHK(c, hipMalloc(&b.bbox_dev, 64));
-    HIPCHK(c, hipMemcpyAsync(b.bbox_dev, init, 64, hipMemcpyHostToDevice, L.s));
-    HIPCHK(c, launch_soa_repack(L.s, (const float*)b.d, n, b.soa, b.bbox_dev));
     uint32_t got[16];
-    HIPCHK(c, hipMemcpyAsync(got, b.bbox_dev, 64, hipMemcpyDeviceToHost, L.s));
-    HIPCHK(c, hipStreamSynchronize(L.s));          // the shadow is complete before any lane can be asked to read it
+    // the compact layout first (every sig the reference builds is symmetric); a record that is not sends the repack round again
+    const bool allow_compact = !(getenv("GS4D_SOA_FULL") && atoi(getenv("GS4D_SOA_FULL")));             // test hook: always the 96-byte layout (upload-time code: read per repack)
+    for (int attempt = allow_compact ? 0 : 1; attempt < 2; ++attempt) {
+        b.soa_compact = attempt == 0;
+        HIPCHK(c, hipMemcpyAsync(b.bbox_dev, init, 64, hipMemcpyHostToDevice, L.s));
+        HIPCHK(c, launch_soa_repack(L.s, (const float*)b.d, n, b.soa, b.bbox_dev, b.soa_compact));
+        HIPCHK(c, hipMemcpyAsync(got, b.bbox_dev, 64, hipMemcpyDeviceToHost, L.s));
+        HIPCHK(c, hipStreamSynchronize(L.s));      // the shadow is complete before any lane can be asked to read it
+        if (!b.soa_compact || got[15] == 0) break;
+    }
     auto ord2f = [](uint32_t u) { u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &u, 4); return (double)f; };
     b.bb_ok = n > 0 && got[14] == 0;
     for (int k = 0; k < 7; ++k) { b.bb_lo[k] = ord2f(got[k]); b.bb_hi[k] = ord2f(got[7 + k]); if (!(b.bb_lo[k] <= b.bb_hi[k])) b.bb_ok = false; }
@@ -338,7 +345,9 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
     {
         StageTimer t(c, GS4D_T_BINNING);
         HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
-        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world));
+        const uint32_t* fused_keys = nullptr;
+        if (a.fuse) { Buffer* K = getbuf(c, a.fuse_keys); if (K) fused_keys = (const uint32_t*)K->d; }      // the projection wrote the keys there and nowhere else
+        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, fused_keys, a.ks.bias, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world));
         HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
     }
     c->stat_tile_passes = 0;
@@ -423,7 +432,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
-            else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, data->soa_n, npre, a.u, c->W, c->H, po, tc));
+            else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, data->soa_n, data->soa_compact, npre, a.u, c->W, c->H, po, tc));
         }
         L.proj_n = npre;
         if (regen) {
@@ -441,7 +450,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             if (!kh) return hipfail(c, he, "sort_hist_slot");
             const float cam[3] = { a.ks.camx, a.ks.camy, a.ks.camz };
             float view[16] = { 0 }; view[2] = a.ks.vr0; view[6] = a.ks.vr1; view[10] = a.ks.vr2; view[14] = a.ks.vr3;
-            HIPCHK(c, launch_keygen(L.s, data->soa, data->soa + 5 * data->soa_n, npre, a.ks.t, cam, view, a.ks.mode == KEYSRC_VIEWZ ? GS4D_KEY_VIEW_Z : GS4D_KEY_REF_INV_EUCLID,
+            HIPCHK(c, launch_keygen(L.s, data->soa, soa_sig3(data->soa, data->soa_n, data->soa_compact), npre, a.ks.t, cam, view, a.ks.mode == KEYSRC_VIEWZ ? GS4D_KEY_VIEW_Z : GS4D_KEY_REF_INV_EUCLID,
                                     (float*)L.regen_keys, L.order_copy, kh, a.ks.bias, 0xFFFFFFFFu, L.host_total_dev + 4));
             L.depth_sort.hist_bias = a.ks.bias;
             HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, L.regen_keys, L.order_copy, npre, nullptr, a.keybits, true));
@@ -567,7 +576,7 @@ int flush_order(gs4d_ctx* c) {
         uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, po.n, &he);
         if (!kh) return hipfail(c, he, "sort_hist_slot");
         StageTimer tm(c, GS4D_T_KEYGEN);
-        HIPCHK(c, launch_keygen(L.s, D->soa, D->soa + 5 * D->soa_n, po.n, po.t, po.cam, po.view, po.key_mode, (float*)K->d, (uint32_t*)I->d, kh, po.bias, po.span, L.host_total_dev + 4));
+        HIPCHK(c, launch_keygen(L.s, D->soa, soa_sig3(D->soa, D->soa_n, D->soa_compact), po.n, po.t, po.cam, po.view, po.key_mode, (float*)K->d, (uint32_t*)I->d, kh, po.bias, po.span, L.host_total_dev + 4));
         L.depth_sort.hist_bias = po.bias;
     }
     if (po.sorted) {

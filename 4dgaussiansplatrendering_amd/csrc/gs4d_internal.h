@@ -137,7 +137,8 @@ void tile_lists_free(TileLists& t);
 // total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list,
 // [6] workgroups of k_bucket_tiles that have finished, [7] of k_bucket_scan (back to 0 when the kernel ends); total_host (pinned, mapped) receives [0..3] and the longest list at [5]
 hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap);
-hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
+// skey == nullptr: the blend keys the projection left in t.skey; else an array of key bit patterns from which skey_bias is still to be subtracted (the caller's key buffer of a fused draw)
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint);
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs);
@@ -169,10 +170,13 @@ template <class F> __device__ __forceinline__ void for_each_tile(const TRect& r,
 #endif
 
 // ---- preprocess.hip ----
-hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* 6 planes of n float4 */, uint32_t* bbox /* [16], preset: min = ~0, max = 0 */);
+// compact: the 72-byte layout of a symmetric sig (preprocess.hip); bbox[15] comes back non-zero if some record's sig is NOT symmetric bit for bit
+// (the caller then repacks in the full layout).  Either way plane 0 is pos and soa_sig3() is the plane of sig[3] (what key generation reads).
+hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* n * 96 bytes */, uint32_t* bbox /* [16], preset: min = ~0, max = 0 */, bool compact);
+inline const float4* soa_sig3(const float4* soa, size_t n, bool compact) { return soa + (compact ? 3 : 5) * n; }
 // Each preprocess launch also writes the compact pixel rectangle of every record.
 struct PreOut { float4* proj; uint2* rects; };
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n /* records in the buffer: the plane stride */, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n /* records in the buffer: the plane stride */, bool compact, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 

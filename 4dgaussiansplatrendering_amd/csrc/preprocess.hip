@@ -9,15 +9,22 @@
 // (cx, cy, a0, a1) is bit-identical to the CPU checker, which evaluates the same expressions in the same order.
 #include "gs4d_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace gs4d {
 
-// AoS 96-B SplatData (Scenes.h:22-37) -> 6 planes of float4: pos, col, sig[0], sig[1], sig[2], sig[3]
+// AoS 96-B SplatData (Scenes.h:22-37) -> planes.  Two layouts (SoaLayout, gs4d_internal.h):
+//   full     6 planes of float4: pos, col, sig[0], sig[1], sig[2], sig[3]                                                 96 B / record
+//   compact  pos, col, U = (s00, s01, s02, s11), V = sig[3] = (s03, s13, s23, s33) as float4 planes, W = (s12, s22) as a float2 plane   72 B / record
+// The compact one holds a SYMMETRIC sig without its mirrored half — every covariance the reference builds is one (Splat.h:127, 141-154) —
+// bit for bit: the repack kernel compares sig[c][r] with sig[r][c] as bit patterns for every record and raises bbox[15] if any pair
+// differs; the host then repacks in the full layout.  A quarter of the projection's read traffic is gone for the records the reference makes.
 // float <-> unsigned with the same order, for atomicMin/atomicMax on floats
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
 // Also reduces the bounding box of what the sort key depends on — position, mu_t and the velocity column sig[3].xyz
 // (Scenes.h:28-36) — into bbox[0..6] = min, bbox[7..13] = max (order-preserving uint form), bbox[14] = non-finite input seen.
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ soa, uint32_t* __restrict__ bbox) {
     // one wave moves 64 records = 384 float4, read fully coalesced, written as 6 x 64 contiguous float4
     __shared__ float4 stage[4][384];
@@ -28,7 +35,7 @@ __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ a
     uint32_t lo[7], hi[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) { lo[k] = 0xFFFFFFFFu; hi[k] = 0u; }
-    bool bad = false;
+    bool bad = false, asym = false;
     for (uint32_t chunk = blockIdx.x; chunk * 256u < n; chunk += gridDim.x) {           // uniform trip count per workgroup
         const uint32_t rec0 = (chunk * 4u + w) * 64u;
         const uint32_t nrec = rec0 < n ? min(64u, n - rec0) : 0u;
@@ -39,8 +46,20 @@ __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ a
         }
         __builtin_amdgcn_wave_barrier();               // stage[w] is private to the wave
         if (lane < nrec) {
+            if (COMPACT) {
+                const float4 c0 = stage[w][lane * 6u + 2], c1 = stage[w][lane * 6u + 3], c2 = stage[w][lane * 6u + 4], c3 = stage[w][lane * 6u + 5];
+                soa[rec0 + lane] = stage[w][lane * 6u + 0];
+                soa[(size_t)n + rec0 + lane] = stage[w][lane * 6u + 1];
+                soa[(size_t)2 * n + rec0 + lane] = make_float4(c0.x, c0.y, c0.z, c1.y);
+                soa[(size_t)3 * n + rec0 + lane] = c3;
+                reinterpret_cast<float2*>(soa + (size_t)4 * n)[rec0 + lane] = make_float2(c1.z, c2.z);
+                auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b); };
+                // sig[c][r] == sig[r][c]: c0.y = sig[0][1] vs c1.x = sig[1][0], ...
+                if (!(same(c0.y, c1.x) && same(c0.z, c2.x) && same(c0.w, c3.x) && same(c1.z, c2.y) && same(c1.w, c3.y) && same(c2.w, c3.z))) asym = true;
+            } else {
 #pragma unroll
-            for (int p = 0; p < 6; ++p) soa[(size_t)p * n + rec0 + lane] = stage[w][lane * 6u + p];
+                for (int p = 0; p < 6; ++p) soa[(size_t)p * n + rec0 + lane] = stage[w][lane * 6u + p];
+            }
             const float4 ps = stage[w][lane * 6u + 0], s3 = stage[w][lane * 6u + 5];
             const float q[7] = { ps.x, ps.y, ps.z, ps.w, s3.x, s3.y, s3.z };
 #pragma unroll
@@ -57,6 +76,7 @@ __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ a
         for (int off = 32; off > 0; off >>= 1) { lo[k] = min(lo[k], (uint32_t)__shfl_xor(lo[k], off, 64)); hi[k] = max(hi[k], (uint32_t)__shfl_xor(hi[k], off, 64)); }
     }
     const bool anybad = __ballot(bad) != 0ull;
+    if (COMPACT && __ballot(asym) != 0ull && lane == 0) atomicOr(&bbox[15], 1u);
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) { red[w][k] = lo[k]; red[w][7 + k] = hi[k]; }
@@ -71,15 +91,16 @@ __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ a
     }
 }
 
-hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa, uint32_t* bbox) {
+hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa, uint32_t* bbox, bool compact) {
     if (n == 0) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
-    k_soa_repack<<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox);
+    if (compact) k_soa_repack<true><<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox);
+    else k_soa_repack<false><<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox);
     return hipGetLastError();
 }
 
 // ---- shared device math (same expression order as the checker) ----------------------------------
-struct PU { float V[16]; float P[16]; float time, min_opacity; int W, H; };
+struct PU { float V[16]; float P[16]; float time, min_opacity; int W, H; int store_d; };
 
 __device__ __forceinline__ float maxf_glsl(float a, float b) { return a >= b ? a : b; }
 __device__ __forceinline__ void normalize2(float& x, float& y) { float tx = x * x, ty = y * y; float s = 1.0f / sqrtf(tx + ty); x = x * s; y = y * s; }
@@ -109,7 +130,7 @@ __device__ __forceinline__ bool fin(float x) { return isfinite(x); }
 
 // Window-space set-up + record store.  ncx,ncy = NDC centre; kx,ky = NDC scale of the quad offset.
 __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid, const Quad& q, float ncx, float ncy, float kx, float ky,
-                                      int W, int H, float r, float g, float b, float alpha, bool clamp_rgb) {
+                                      int W, int H, float r, float g, float b, float alpha, bool clamp_rgb, int store_d) {
     float cx = 0, cy = 0, a0x = 0, a0y = 0, a1x = 0, a1y = 0, hx = 0, hy = 0;
     uint32_t rect0 = 1u, rect1 = 0u;           // empty
     if (valid) {
@@ -146,7 +167,7 @@ __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid,
     o[0] = make_float4(cx, cy, a0x, a0y);
     o[1] = make_float4(a1x, a1y, alpha, r);
     o[2] = make_float4(g, b, __uint_as_float(rect0), __uint_as_float(rect1));
-    o[3] = make_float4(hx, hy, valid ? 1.0f : 0.0f, 0.0f);
+    if (store_d) o[3] = make_float4(hx, hy, valid ? 1.0f : 0.0f, 0.0f);       // read by nothing but gs4d_debug_read_projected
     return make_uint2(rect0, rect1);
 }
 
@@ -241,14 +262,29 @@ __device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float
 
 // One record each: returns its pixel rectangle, and through `key` its blend-order key (unordered path).
 struct Src4D { const float4* soa; uint32_t stride; };      // six planes of `stride` float4 (the buffer's record count, not the draw's)
+struct Src4DSym { const float4* soa; uint32_t stride; };   // the compact layout of a symmetric sig: pos, col, U, V as float4 planes, W as a float2 plane
 struct Src3D { const float* verts; };
 struct Src2D { const float* recs; };
 
+__device__ __forceinline__ uint2 project_4d(const float4& pos, const float4& col, const float4& s0, const float4& s1, const float4& s2, const float4& s3,
+                                            uint32_t i, const PU& u, const PreOut& out, const KeySrc& ks, uint32_t& key);
 __device__ __forceinline__ uint2 project_record(const Src4D& src, uint32_t n, uint32_t i, const PU& u, const PreOut& out, const KeySrc& ks, uint32_t& key) {
     const float4* __restrict__ soa = src.soa;
     const size_t ps = src.stride;
     const float4 pos = soa[i], col = soa[ps + i];
     const float4 s0 = soa[2 * ps + i], s1 = soa[3 * ps + i], s2 = soa[4 * ps + i], s3 = soa[5 * ps + i];
+    return project_4d(pos, col, s0, s1, s2, s3, i, u, out, ks, key);
+}
+__device__ __forceinline__ uint2 project_record(const Src4DSym& src, uint32_t n, uint32_t i, const PU& u, const PreOut& out, const KeySrc& ks, uint32_t& key) {
+    const float4* __restrict__ soa = src.soa;
+    const size_t ps = src.stride;
+    const float4 pos = soa[i], col = soa[ps + i], U = soa[2 * ps + i], V = soa[3 * ps + i];
+    const float2 W = reinterpret_cast<const float2*>(soa + 4 * ps)[i];
+    // sig[c] = column c; the mirrored elements are the same bits (verified by the repack kernel)
+    return project_4d(pos, col, make_float4(U.x, U.y, U.z, V.x), make_float4(U.y, U.w, W.x, V.y), make_float4(U.z, W.x, W.y, V.z), V, i, u, out, ks, key);
+}
+__device__ __forceinline__ uint2 project_4d(const float4& pos, const float4& col, const float4& s0, const float4& s1, const float4& s2, const float4& s3,
+                                            uint32_t i, const PU& u, const PreOut& out, const KeySrc& ks, uint32_t& key) {
     float s44 = s3.w;
     float dt = u.time - pos.w;
     float ot = maxf_glsl(expf(-0.5f * dt * (1.0f / s44) * dt), u.min_opacity);     // :48-51, 83
@@ -267,7 +303,7 @@ __device__ __forceinline__ uint2 project_record(const Src4D& src, uint32_t n, ui
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, mx, my, mz, C, q, ncx, ncy);
     key = blend_key_4d(ks, i, pos, s3);
-    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w, true);
+    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, col.x, col.y, col.z, ot * col.w, true, u.store_d);
 }
 
 __device__ __forceinline__ uint2 project_record(const Src3D& src, uint32_t, uint32_t i, const PU& u, const PreOut& out, const KeySrc&, uint32_t& key) {
@@ -280,7 +316,7 @@ __device__ __forceinline__ uint2 project_record(const Src3D& src, uint32_t, uint
     Quad q; float ncx = 0, ncy = 0;
     bool valid = project3d(u, v[2], v[3], v[4], C, q, ncx, ncy);
     key = i;
-    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8], false);
+    return emit(out, i, valid, q, ncx, ncy, u.P[0], u.P[5], u.W, u.H, v[5], v[6], v[7], v[8], false, u.store_d);
 }
 
 __device__ __forceinline__ uint2 project_record(const Src2D& src, uint32_t, uint32_t i, const PU& u, const PreOut& out, const KeySrc&, uint32_t& key) {
@@ -303,7 +339,7 @@ __device__ __forceinline__ uint2 project_record(const Src2D& src, uint32_t, uint
     bool valid = (clipw > 0.0f) && !(clipz < -clipw || clipz > clipw);
     float kx = P[0] / clipw, ky = P[5] / clipw;
     key = i;
-    return emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7], true);
+    return emit(out, i, valid, q, kx * psx, ky * psy, kx, ky, u.W, u.H, rec[4], rec[5], rec[6], rec[7], true, u.store_d);
 }
 
 // One thread per record (the ordered path).
@@ -335,7 +371,8 @@ __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t
         if (i < i1) {
             const uint2 rect = project_record(src, n, i, u, out, tc.ks, key);
             if (COUNT) {
-                tc.skey[i] = key;
+                if (!FUSE_KEYS) tc.skey[i] = key;                             // fused: k_bucket_scatter takes the key from the caller's key buffer, written just below
+
                 r = tile_rect(rect.x, rect.y, (uint32_t)tc.shard_rank, (uint32_t)tc.shard_world);
             }
             if (FUSE_KEYS) {
@@ -356,6 +393,8 @@ static PU make_pu(const Uniforms& un, int W, int H) {
     PU u;
     for (int i = 0; i < 16; ++i) { u.V[i] = un.view[i]; u.P[i] = un.proj[i]; }
     u.time = un.time; u.min_opacity = un.min_opacity; u.W = W; u.H = H;
+    static const int store_d = getenv("GS4D_PROJ_D") ? atoi(getenv("GS4D_PROJ_D")) : 1;      // experiment: 0 leaves the record's fourth float4 unwritten
+    u.store_d = store_d;
     return u;
 }
 
@@ -373,7 +412,9 @@ static hipError_t launch_pre(hipStream_t st, SRC src, size_t n, const Uniforms& 
     else k_preprocess<SRC><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src4D{ soa, (uint32_t)soa_n }, n, un, W, H, out, tc); }
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n, bool compact, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
+    return compact ? launch_pre(st, Src4DSym{ soa, (uint32_t)soa_n }, n, un, W, H, out, tc) : launch_pre(st, Src4D{ soa, (uint32_t)soa_n }, n, un, W, H, out, tc);
+}
 hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src3D{ verts72 }, n, un, W, H, out, tc); }
 hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src2D{ rec48 }, n, un, W, H, out, tc); }
 

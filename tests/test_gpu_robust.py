@@ -220,3 +220,46 @@ def test_clear_colour_set_after_a_draw_does_not_repaint_its_rerun(gs4d, oracle, 
     ctx.clear()
     assert np.array_equal(ctx.read_pixels()[0, 0], np.array([1.0, 0.0, 1.0, 1.0], np.float32))
     ctx.close()
+
+
+def test_compact_and_full_record_shadows(gs4d, oracle, monkeypatch):
+    """The private SoA shadow of the records keeps a symmetric sig without its mirrored half (72 bytes a record instead of 96).  Symmetric
+    records: both layouts give the same projected records and the same image, bit for bit.  A record whose sig is NOT symmetric must make
+    the library fall back to the full layout — the shader reads iSig[c][r] where it reads it (…Instanced.GLSL:84-95), mirrored or not."""
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    from test_gpu_render import gpu_frame, check_projected
+    n, W, H = 20000, 640, 360
+    pos4, q, sc, life, fade, vel, rgba = scenes.cube_params_4d(n, seed=21)
+    rec = gs4d.build_records_4d(pos4, q, sc * 3.0, life * 20.0, fade, vel, rgba)
+    sig = rec[:, 8:].reshape(-1, 4, 4)
+    assert np.array_equal(sig, sig.transpose(0, 2, 1))
+    cam = scenes.CAM_CUBE
+    t = 20.0
+    out = {}
+    for full in (0, 1):
+        monkeypatch.setenv("GS4D_SOA_FULL", str(full))           # read at every repack
+        ctx = gs4d.Context(W, H)
+        img, projd, _, (view, proj) = gpu_frame(ctx, gs4d, rec, cam, t=t)
+        ctx.close()
+        out[full] = (img, projd)
+    eproj = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, 0.0)
+    for full in (0, 1):
+        check_projected(oracle, out[full][1], eproj)
+    assert np.array_equal(out[0][0], out[1][0])
+    eimg, _, _ = oracle.render_4d(rec, True, t, 0.0, cam[0], view, proj, W, H)
+    assert linf(out[0][0], eimg) <= TOL
+    # not symmetric: every 7th record gets another iSig[0][1] (and keeps iSig[1][0]), every 11th another iSig[2][3]
+    rec2 = rec.copy()
+    rec2[::7, 8 + 1] *= 1.25
+    rec2[::11, 8 + 4 * 2 + 3] += 0.05
+    monkeypatch.delenv("GS4D_SOA_FULL", raising=False)
+    ctx = gs4d.Context(W, H)
+    img2, projd2, _, _ = gpu_frame(ctx, gs4d, rec2, cam, t=t)
+    check_projected(oracle, projd2, oracle.preprocess(oracle.MODE_4D, rec2, view, proj, W, H, t, 0.0))
+    eimg2, _, _ = oracle.render_4d(rec2, True, t, 0.0, cam[0], view, proj, W, H)
+    assert linf(img2, eimg2) <= TOL
+    assert linf(eimg2, eimg) > 1e-3                              # the asymmetry is visible: a compact shadow would have lost it
+    # and back: a symmetric buffer uploaded into the same context uses the compact layout again, same bits as before
+    img3, _, _, _ = gpu_frame(ctx, gs4d, rec, cam, t=t)
+    assert np.array_equal(img3, out[0][0])
+    ctx.close()
