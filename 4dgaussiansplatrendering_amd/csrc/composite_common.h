@@ -11,8 +11,11 @@ namespace gs4d {
 //      phase B, lane = pixel: walks the set bits of its own mask front to back, fetches that entry from LDS and blends.
 //      Work is proportional to the number of covered pixels instead of 64 x entries.
 //  * pixel-parallel broadcast (large footprints, e.g. the teapot scenes): every lane tests every entry of the chunk.
-// Entries whose box covers more than SMALL_AREA pixels of the tile are always tested pixel-parallel.
-constexpr int SMALL_AREA = 16;
+// Entries whose box inside the tile is wider or taller than SMALL_SIDE pixels are always tested pixel-parallel.
+// (Round 2 walked each small box cell by cell up to 16 cells, x fastest, with a row wrap inside the loop: ~25 wave instructions per cell for
+// three nested divergent regions.  A fixed SMALL_SIDE x SMALL_SIDE window walked by two UNIFORM loops — as many rows and columns as the
+// widest box of the chunk has — needs no wrap and keeps everything of a row in registers: ~12 per cell.)
+constexpr int SMALL_SIDE = 4;
 
 // Workgroup -> tile.  Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8) and each XCD has an L2 of its own;
 // a splat that touches several tiles (1.38 entries per splat in the cube configs) is gathered once per tile.  With tile = workgroup id
@@ -61,25 +64,31 @@ __device__ __forceinline__ void blend_general(BlendFn bf, float sr, float sg, fl
 
 // GENERAL = false: the default function (SRC_ALPHA, ONE_MINUS_SRC_ALPHA), accumulated front to back: colour C, transmittance T.
 // GENERAL = true : any function of the menu, applied fragment by fragment in draw order to the pixel's value (Cr, Cg, Cb, A); T unused.
+// exp(-32 q) as ONE multiply and the hardware's 2^x (v_exp_f32); [0, 1] clamps as one v_med3_f32 (finite arguments only reach them).
+__device__ __forceinline__ float gauss_weight(float u, float v) { return __builtin_amdgcn_exp2f((u * u + v * v) * -46.16624130844683f); }      // -32 * log2(e)
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+
 template <bool PREMULT_C, bool GENERAL = false>
 __device__ __forceinline__ void blend_fragment(float u, float v, float alpha, float r_, float g_, float b_, float& T, float& Cr, float& Cg, float& Cb, float& A, BlendFn bf = BlendFn{ 0, 0 }) {
-    const float q = u * u + v * v;
-    const float cg = __expf(-32.0f * q);
-    if (cg >= 0.0001f) {                                   // Splat4DFragShader.GLSL:30 discard
-        if (GENERAL) {
-            const float al = __saturatef(alpha * cg);
-            if (PREMULT_C) { r_ = __saturatef(r_ * cg); g_ = __saturatef(g_ * cg); b_ = __saturatef(b_ * cg); }
+    const float cg = gauss_weight(u, v);
+    if (GENERAL) {
+        if (cg >= 0.0001f) {                               // Splat4DFragShader.GLSL:30 discard
+            const float al = clamp01(alpha * cg);
+            if (PREMULT_C) { r_ = clamp01(r_ * cg); g_ = clamp01(g_ * cg); b_ = clamp01(b_ * cg); }
             blend_general(bf, r_, g_, b_, al, Cr, Cg, Cb, A);
-            return;
         }
-        // The reference blends into a fixed-point (RGBA8) framebuffer: the GL clamps the fragment's colour and alpha to [0, 1] before the
-        // blend (OpenGL 4.4, 17.3.8).  Colours that are not premultiplied were clamped once per record by the projection kernel.
-        const float al = __saturatef(alpha * cg);
-        const float w = T * al;
-        if (PREMULT_C) { r_ = __saturatef(r_ * cg); g_ = __saturatef(g_ * cg); b_ = __saturatef(b_ * cg); }   // Splat3DFragShaderFull.GLSL:22
-        Cr += w * r_; Cg += w * g_; Cb += w * b_; A += w * al;
-        T *= (1.0f - al);
+        return;
     }
+    // The reference blends into a fixed-point (RGBA8) framebuffer: the GL clamps the fragment's colour and alpha to [0, 1] before the
+    // blend (OpenGL 4.4, 17.3.8).  Colours that are not premultiplied were clamped once per record by the projection kernel.
+    // No branch: a discarded fragment (Splat4DFragShader.GLSL:30) — and a lane that has no fragment at all, which passes alpha = 0 — blends
+    // with al = 0, which leaves C and T as they are, exactly (C + 0 * c, T * 1).  The compositor is bound by instruction issue; a divergent
+    // region costs four wave instructions whether or not a lane takes it.
+    const float al = cg >= 0.0001f ? clamp01(alpha * cg) : 0.0f;
+    const float w = T * al;
+    if (PREMULT_C) { r_ = clamp01(r_ * cg); g_ = clamp01(g_ * cg); b_ = clamp01(b_ * cg); }   // Splat3DFragShaderFull.GLSL:22
+    Cr += w * r_; Cg += w * g_; Cb += w * b_; A += w * al;
+    T *= (1.0f - al);
 }
 
 // One chunk of the tile's list, front to back: lane s < cnt carries record `rec` of list entry (end of chunk - 1 - s), so s = 0 is the
@@ -89,7 +98,7 @@ template <bool PREMULT_C, bool GENERAL = false>
 __device__ __forceinline__ void composite_chunk(const float4* __restrict__ proj, uint32_t rec, uint32_t cnt, uint32_t lane, int tx0, int ty0, float fx, float fy,
                                                 float4* stage, uint32_t* pmask, int dbg, float& T, float& Cr, float& Cg, float& Cb, float& A, BlendFn bf = BlendFn{ 0, 0 }) {
     // lane s holds list entry hi-1-s : s = 0 is the LAST (front-most) entry of this chunk
-    int lx0 = 0, ly0 = 0, bw = 0, area = 0;
+    int lx0 = 0, ly0 = 0, bw = 0, bh = 0;
     float4 ra = make_float4(0, 0, 0, 0), rb = ra;
     if (lane < cnt) {
         const float4* r = proj + (size_t)rec * 4;
@@ -102,52 +111,54 @@ __device__ __forceinline__ void composite_chunk(const float4* __restrict__ proj,
         lx0 = max((int)(r0 & 0xFFFFu) - tx0, 0); ly0 = max((int)(r0 >> 16) - ty0, 0);
         const int lx1 = min((int)(r1 & 0xFFFFu) - tx0, TILE - 1), ly1 = min((int)(r1 >> 16) - ty0, TILE - 1);
         bw = lx1 - lx0 + 1;
-        const int bh = ly1 - ly0 + 1;
-        area = (bw > 0 && bh > 0) ? bw * bh : 0;
+        bh = ly1 - ly0 + 1;
+        if (bw <= 0 || bh <= 0) { bw = 0; bh = 0; }            // no pixel of this tile (cannot happen for a list entry; kept exact)
     }
-    const bool big = area > SMALL_AREA;
+    const bool big = bw > SMALL_SIDE || bh > SMALL_SIDE;
     const uint64_t bigmask = __ballot(big);
     pmask[lane * 2] = 0u; pmask[lane * 2 + 1] = 0u;
     __syncthreads();
     if (dbg != 2 && (dbg == 1 || (uint32_t)__popcll(bigmask) * 2u > cnt)) {
         // ---- pixel-parallel broadcast over the whole chunk ----
         for (uint32_t s = 0; s < cnt; ++s) {
-            const float4 a = stage[s * 3 + 0];          // cx, cy, a0x, a0y      (uniform address: LDS broadcast)
-            const float4 b = stage[s * 3 + 1];          // a1x, a1y, alpha, r
+            const float4 a = stage[s * 3 + 0];          // cx, cy, a0x, a1x      (uniform address: LDS broadcast)
+            const float4 b = stage[s * 3 + 1];          // a0y, a1y, r, g
             const float dx = __fsub_rn(fx, a.x), dy = __fsub_rn(fy, a.y);
-            const float u = __fmaf_rn(a.z, dx, __fmul_rn(a.w, dy));
-            const float v = __fmaf_rn(b.x, dx, __fmul_rn(b.y, dy));
+            const float u = __fmaf_rn(a.z, dx, __fmul_rn(b.x, dy));
+            const float v = __fmaf_rn(a.w, dx, __fmul_rn(b.y, dy));
             const bool cov = fabsf(u) <= 0.5f && fabsf(v) <= 0.5f;
             if (__ballot(cov) == 0ull) continue;
-            const float4 c = stage[s * 3 + 2];          // g, b, -, -
-            if (cov) blend_fragment<PREMULT_C, GENERAL>(u, v, b.z, b.w, c.x, c.y, T, Cr, Cg, Cb, A, bf);
+            const float4 c = stage[s * 3 + 2];          // b, alpha, -, -
+            if (cov) blend_fragment<PREMULT_C, GENERAL>(u, v, c.y, b.z, b.w, c.x, T, Cr, Cg, Cb, A, bf);
         }
     } else {
         // ---- phase A (lane = entry): mark the covered pixels of small footprints ----
-        // The box is walked x fastest with everything that does not change along a row kept in registers.  The values are the same bits as
-        // evaluating (float)(pixel) + 0.5f afresh: pixel centres are integers + 0.5 below 2^16, adding 1.0f to them is exact.  (The
-        // compositor is bound by VALU issue: this loop is a third of a chunk's instructions.)
-        const int small_area = big ? 0 : area;
-        const float fx0 = (float)(tx0 + lx0) + 0.5f;
-        float fxq = fx0, fyq = (float)(ty0 + ly0) + 0.5f;
-        float dyq = __fsub_rn(fyq, ra.y);
-        float t0 = __fmul_rn(ra.w, dyq), t1 = __fmul_rn(rb.y, dyq);
-        uint32_t* pm = pmask + (ly0 * TILE + lx0) * 2 + (int)(lane >> 5);
+        // The box is at most SMALL_SIDE x SMALL_SIDE here.  Two uniform loops, over as many rows and columns as the tallest / widest small box
+        // of the chunk: what does not change along a row stays in registers, and (float)(pixel) + 0.5f is formed afresh for every cell —
+        // the same bits the pixel-parallel path and the checker use (pixel centres are integers + 0.5 below 2^16: exact).
+        const int sw = big ? 0 : bw, sh = big ? 0 : bh;
+        // the widest / tallest small box of the chunk, by ballots (scalar work: the vector pipe is the bottleneck here)
+        int mw = 0, mh = 0;
+#pragma unroll
+        for (int k = 0; k < SMALL_SIDE; ++k) { if (__ballot(sw > k) != 0ull) mw = k + 1; if (__ballot(sh > k) != 0ull) mh = k + 1; }
+        const float fx0 = (float)(tx0 + lx0) + 0.5f, fy0 = (float)(ty0 + ly0) + 0.5f;
+        uint32_t* const pm0 = pmask + (ly0 * TILE + lx0) * 2 + (int)(lane >> 5);
         const uint32_t bit = 1u << (lane & 31u);
-        int ix = 0;
-        for (int k = 0; k < SMALL_AREA; ++k) {
-            const bool act = k < small_area;
-            if (__ballot(act) == 0ull) break;
-            if (act) {
-                const float dx = __fsub_rn(fxq, ra.x);
-                const float u = __fmaf_rn(ra.z, dx, t0);
-                const float v = __fmaf_rn(rb.x, dx, t1);
-                if (fabsf(u) <= 0.5f && fabsf(v) <= 0.5f) atomicOr(pm + 2 * ix, bit);
-                fxq += 1.0f;
-                if (++ix == bw) {
-                    ix = 0; fxq = fx0; fyq += 1.0f; pm += 2 * TILE;
-                    dyq = __fsub_rn(fyq, ra.y); t0 = __fmul_rn(ra.w, dyq); t1 = __fmul_rn(rb.y, dyq);
-                }
+        float dxs[SMALL_SIDE];
+#pragma unroll
+        for (int xx = 0; xx < SMALL_SIDE; ++xx) dxs[xx] = __fsub_rn(fx0 + (float)xx, ra.x);
+#pragma unroll
+        for (int yy = 0; yy < SMALL_SIDE; ++yy) {
+            if (yy >= mh) break;                            // uniform
+            const float dyq = __fsub_rn(fy0 + (float)yy, ra.y);
+            const float t0 = __fmul_rn(rb.x, dyq), t1 = __fmul_rn(rb.y, dyq);
+            const bool rowin = yy < sh;
+#pragma unroll
+            for (int xx = 0; xx < SMALL_SIDE; ++xx) {
+                if (xx >= mw) break;                        // uniform
+                const float u = __fmaf_rn(ra.z, dxs[xx], t0);
+                const float v = __fmaf_rn(ra.w, dxs[xx], t1);
+                if (rowin && xx < sw && fabsf(u) <= 0.5f && fabsf(v) <= 0.5f) atomicOr(pm0 + (yy * TILE + xx) * 2, bit);
             }
         }
         // ---- large footprints of this chunk: every pixel tests them itself ----
@@ -157,25 +168,27 @@ __device__ __forceinline__ void composite_chunk(const float4* __restrict__ proj,
             const float4 a = stage[e * 3 + 0];
             const float4 b = stage[e * 3 + 1];
             const float dx = __fsub_rn(fx, a.x), dy = __fsub_rn(fy, a.y);
-            const float u = __fmaf_rn(a.z, dx, __fmul_rn(a.w, dy));
-            const float v = __fmaf_rn(b.x, dx, __fmul_rn(b.y, dy));
+            const float u = __fmaf_rn(a.z, dx, __fmul_rn(b.x, dy));
+            const float v = __fmaf_rn(a.w, dx, __fmul_rn(b.y, dy));
             if (fabsf(u) <= 0.5f && fabsf(v) <= 0.5f) mine |= 1ull << e;
         }
         __syncthreads();
         // ---- phase B (lane = pixel): blend the entries that hit this pixel, front to back ----
+        // One straight body per round (GENERAL keeps its branch: the blend functions of the menu are not the hot path): a pixel that has run
+        // out of hits reads entry 0 and blends it with alpha 0 — nothing changes, and no divergent region is opened.
         uint64_t m = mine | (uint64_t)pmask[lane * 2] | ((uint64_t)pmask[lane * 2 + 1] << 32);
         while (__ballot(m != 0ull) != 0ull) {
-            if (m != 0ull) {
-                const int e = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                const float4 a = stage[e * 3 + 0];
-                const float4 b = stage[e * 3 + 1];
-                const float4 c = stage[e * 3 + 2];
-                const float dx = __fsub_rn(fx, a.x), dy = __fsub_rn(fy, a.y);
-                const float u = __fmaf_rn(a.z, dx, __fmul_rn(a.w, dy));
-                const float v = __fmaf_rn(b.x, dx, __fmul_rn(b.y, dy));
-                blend_fragment<PREMULT_C, GENERAL>(u, v, b.z, b.w, c.x, c.y, T, Cr, Cg, Cb, A, bf);
-            }
+            const bool on = m != 0ull;
+            const int e = on ? __ffsll((long long)m) - 1 : 0;
+            m &= m - 1ull;                                  // 0 stays 0
+            const float4 a = stage[e * 3 + 0];
+            const float4 b = stage[e * 3 + 1];
+            const float4 c = stage[e * 3 + 2];
+            const float dx = __fsub_rn(fx, a.x), dy = __fsub_rn(fy, a.y);
+            const float u = __fmaf_rn(a.z, dx, __fmul_rn(b.x, dy));
+            const float v = __fmaf_rn(a.w, dx, __fmul_rn(b.y, dy));
+            if (GENERAL) { if (on) blend_fragment<PREMULT_C, true>(u, v, c.y, b.z, b.w, c.x, T, Cr, Cg, Cb, A, bf); }
+            else blend_fragment<PREMULT_C, false>(u, v, on ? c.y : 0.0f, b.z, b.w, c.x, T, Cr, Cg, Cb, A);
         }
     }
     __syncthreads();

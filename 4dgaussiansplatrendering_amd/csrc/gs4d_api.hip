@@ -427,7 +427,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
                 hipError_t he = hipSuccess;
                 uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, npre, &he);
                 if (!kh) return hipfail(c, he, "sort_hist_slot");
-                tc.keys_out = (float*)K->d; tc.idx_out = (uint32_t*)I->d; tc.ghist = kh; tc.span = a.fuse_span; tc.err = L.host_total_dev + 4;
+                tc.keys_out = (float*)K->d; tc.idx_out = nullptr /* the depth sort below makes the identity index up */; (void)I; tc.ghist = kh; tc.span = a.fuse_span; tc.err = L.host_total_dev + 4;
                 L.depth_sort.hist_bias = a.ks.bias;
             }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
@@ -461,7 +461,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             // histograms) and the binning (which reads the sorted index)
             Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
             StageTimer t(c, GS4D_T_SORT);
-            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true));
+            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true, true));
         }
     }
     size_t want = a.instances * 2 + 65536;
@@ -474,7 +474,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             // waits for it (the draw took its order from the keys), it fills the caller's buffers for whoever reads them next
             Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
             StageTimer t(c, GS4D_T_SORT);
-            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true));
+            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true, true));
         }
         return rc;
     }
@@ -1284,7 +1284,13 @@ int gs4d_debug_read_projected(gs4d_ctx* c, float* out16, size_t nrecords) {
     int rc = resolve_pending(c); if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(out16, L.proj, nrecords * 64, hipMemcpyDeviceToHost, L.s));
     HIPCHK(c, hipStreamSynchronize(L.s));
-    // expose the layout documented in gs4d.h: cx,cy,a0x,a0y,a1x,a1y,alpha,r,g,b,rect0,rect1,hx,hy,valid,0  (already the storage order)
+    // expose the layout documented in gs4d.h: cx,cy,a0x,a0y,a1x,a1y,alpha,r,g,b,rect0,rect1,hx,hy,valid,0
+    // stored (gs4d_internal.h):               cx,cy,a0x,a1x,a0y,a1y,r,g,b,alpha,rect0,rect1,hx,hy,valid,0
+    for (size_t i = 0; i < nrecords; ++i) {
+        float* r = out16 + 16 * i;
+        const float a1x = r[3], a0y = r[4], cr = r[6], cg = r[7], cb = r[8], al = r[9];
+        r[3] = a0y; r[4] = a1x; r[6] = al; r[7] = cr; r[8] = cg; r[9] = cb;
+    }
     return GS4D_OK;
 }
 

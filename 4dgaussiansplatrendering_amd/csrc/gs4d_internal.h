@@ -13,8 +13,8 @@ constexpr int TILE = 8;             // 8x8-pixel tiles: one wave64 composites on
 constexpr int PROJ_FLOATS = 16;     // projected record: 64 B, one aligned segment per splat
 
 // Projected record layout (float4 A,B,C,D), written by preprocess, gathered by binning/composite.
-//  A = cx, cy, a0x, a0y      B = a1x, a1y, alpha, r      C = g, b, rect0 (x0 | y0<<16), rect1 (x1 | y1<<16)   [pixel rect, inclusive]
-//  D = hx, hy, valid(1/0), 0
+//  A = cx, cy, a0x, a1x      B = a0y, a1y, r, g      C = b, alpha, rect0 (x0 | y0<<16), rect1 (x1 | y1<<16)   [pixel rect, inclusive]
+//  D = hx, hy, valid(1/0), 0      (gs4d_debug_read_projected hands them out in the order documented in gs4d.h)
 // rect0 > rect1 in x (x0 = 1, x1 = 0) marks "no coverage".
 
 struct Uniforms {
@@ -44,7 +44,9 @@ void sort_scratch_free(SortScratch& s);
 // Stable LSD radix sort of (key,val) pairs on bits [0, key_bits).  n_dev == nullptr: n is exact.  Otherwise the element
 // count is read on the device from *n_dev (<= n, n is the launch capacity); the result always lands back in keys/vals.
 // have_hist: the digit histograms of `keys` were already accumulated (by the kernel that wrote the keys) into sort_hist_slot(s).
-hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist);
+// identity_vals: the payload is the identity index 0..n-1 and `vals` has NOT been written: the first pass that moves keys makes the indices up
+// instead of reading them (4 bytes per key less to write for whoever produced the keys, 4 less to read here).
+hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals = false);
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
 hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
 hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,

@@ -164,9 +164,10 @@ __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid,
     if (clamp_rgb) { r = __saturatef(r); g = __saturatef(g); b = __saturatef(b); }
     out.rects[i] = make_uint2(rect0, rect1);
     float4* o = out.proj + (size_t)i * 4;
-    o[0] = make_float4(cx, cy, a0x, a0y);
-    o[1] = make_float4(a1x, a1y, alpha, r);
-    o[2] = make_float4(g, b, __uint_as_float(rect0), __uint_as_float(rect1));
+    // (x components of the two affine rows side by side, likewise y: the compositor forms u and v with packed two-float instructions)
+    o[0] = make_float4(cx, cy, a0x, a1x);
+    o[1] = make_float4(a0y, a1y, r, g);
+    o[2] = make_float4(b, alpha, __uint_as_float(rect0), __uint_as_float(rect1));
     if (store_d) o[3] = make_float4(hx, hy, valid ? 1.0f : 0.0f, 0.0f);       // read by nothing but gs4d_debug_read_projected
     return make_uint2(rect0, rect1);
 }
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t
             }
             if (FUSE_KEYS) {
                 tc.keys_out[i] = __uint_as_float(key + tc.ks.bias);          // the blend key is the depth key's bit pattern relative to the bias
-                tc.idx_out[i] = i;
+                if (tc.idx_out) tc.idx_out[i] = i;                            // null: the sort that follows makes up the identity payload itself (radix_sort_pairs)
                 if (key > tc.span) __hip_atomic_store(tc.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // below the bias wraps to a huge value: caught too
             }
         }

@@ -142,13 +142,16 @@ __global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ ke
 // executed passes is 0, 2, 3 or 4 and the result always lands in buffer 0.
 // `live` is a register copy of the workgroup's live mask (bit q: pass q moves keys): every thread derives the same schedule from
 // the same word — nothing is amended in shared memory, so waves cannot disagree about it.
-__device__ __forceinline__ bool os_schedule(uint32_t live, int passes, int p, int& src, int& dst) {
+// `executed` = how many passes move keys before pass p (0: pass p is the first to read the caller's buffers), `total` = how many do at all.
+__device__ __forceinline__ bool os_schedule(uint32_t live, int passes, int p, int& src, int& dst, int& executed, int& total) {
     const uint32_t all = (1u << passes) - 1u;
     live &= all;
     int k = __popc(live);
     if (k == 1) { const uint32_t deadm = all & ~live; live |= deadm & (0u - deadm); ++k; }      // revive the first dead pass (passes >= 2)
-    if (!((live >> p) & 1u)) return false;
+    total = k;
     const int j = __popc(live & ((1u << p) - 1u));
+    executed = j;
+    if (!((live >> p) & 1u)) return false;
     // buffer after i executed passes: even k: 0,1,0,1,...   odd k (>= 3): 0,1,2,0,1,0,...
     auto buf_at = [k](int i) { if (k & 1) { if (i <= 2) return i; return (i - 3) & 1; } return i & 1; };
     src = buf_at(j);
@@ -291,7 +294,8 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
                                                      const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
                                                      uint32_t* status /* [tiles][256] */, uint32_t* acc /* [acc_groups + supers][256], zero at launch */, uint32_t* acc_next /* zeroed here */, uint32_t acc_groups, uint32_t acc_words,
                                                      uint32_t epoch, uint32_t* err,
-                                                     uint32_t* ticket /* zero at launch */, uint32_t* ticket_next /* zeroed here */, uint32_t bias, u64* stamps /* tuning aid, may be null */) {
+                                                     uint32_t* ticket /* zero at launch */, uint32_t* ticket_next /* zeroed here */, uint32_t bias, int identity_vals /* the payload is the identity index and has NOT been written: see radix_sort_pairs */,
+                                                     u64* stamps /* tuning aid, may be null */) {
     constexpr uint32_t TILE_KEYS = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
     static_assert(TILE_KEYS < (1u << 14), "tile-level look-back words carry 14-bit counts");
@@ -335,8 +339,13 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     uint32_t tile = s_tile;
     if (tile >= ntiles) return;                                   // uniform
     const int shift = 8 * pass;
-    int src, dst;
-    if (!os_schedule(~s_dead, passes, pass, src, dst)) return;   // uniform: this pass is an identity
+    int src, dst, executed, total;
+    if (!os_schedule(~s_dead, passes, pass, src, dst, executed, total)) {          // uniform: this pass is an identity
+        // an identity payload nobody has written, and no pass at all will move anything (every key is the same): pass 0's launch writes it
+        if (identity_vals && pass == 0 && total == 0) { for (uint32_t i = blockIdx.x * THREADS + tid; i < n; i += gridDim.x * THREADS) bufs.v[0][i] = i; }
+        return;
+    }
+    const bool make_identity = identity_vals && executed == 0;   // uniform: the first pass that moves keys makes up the payload instead of reading it
     const uint32_t* __restrict__ keys_in = bufs.k[src]; const uint32_t* __restrict__ vals_in = bufs.v[src];
     uint32_t* __restrict__ keys_out = bufs.k[dst]; uint32_t* __restrict__ vals_out = bufs.v[dst];
     uint32_t digit_base = 0;
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
             const uint32_t i = wbase + j * 64u + lane;
             const bool valid = i < n;
             key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
-            val[j] = valid ? vals_in[i] : 0u;
+            val[j] = !valid ? 0u : make_identity ? i : vals_in[i];
         }
         if (first) { digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid); first = false; }      // once per workgroup, under the first tile's loads
         OS_STAMP(1);
@@ -563,7 +572,7 @@ uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError
 }
 
 template <int THREADS, int ITEMS, bool ATOMIC_RANK>
-static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist) {
+static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist, bool identity_vals) {
     const uint32_t tile_keys = THREADS * ITEMS;
     const uint32_t tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
     // persistent workgroups: as many as the device holds at once (asked of the runtime once per shape)
@@ -612,7 +621,7 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
         }
         k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(grid), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, acc_base + (s.acc_flip ? acc_words : 0), acc_base + (s.acc_flip ? 0 : acc_words), (uint32_t)cap_groups, (uint32_t)acc_words,
                                                                          s.epoch & 0x3FFFFFFFu,
-                                                                         s.err ? s.err : s.totals, s.totals + 64 + (s.acc_flip ? 1 : 0), s.totals + 64 + (s.acc_flip ? 0 : 1), bias, (stampf && p == stamp_pass) ? stamps : nullptr);
+                                                                         s.err ? s.err : s.totals, s.totals + 64 + (s.acc_flip ? 1 : 0), s.totals + 64 + (s.acc_flip ? 0 : 1), bias, identity_vals ? 1 : 0, (stampf && p == stamp_pass) ? stamps : nullptr);
         s.acc_flip ^= 1;
     }
     if (stampf && stamps) {   // tuning aid: dump per-tile wall-clock stamps (100 MHz) of one pass
@@ -626,8 +635,8 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     return hipGetLastError();
 }
 
-hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist) {
-    if (n <= 1) return hipSuccess;                    // radix_sort.hpp:260
+hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals) {
+    if (n <= 1) { if (n == 1 && identity_vals) return hipMemsetAsync(vals, 0, 4, st); return hipSuccess; }      // radix_sort.hpp:260
     if (n >= (1ull << 32) - 1) return hipErrorInvalidValue;
     hipError_t e = sort_scratch_reserve(st, s, n);
     if (e != hipSuccess) return e;
@@ -635,7 +644,7 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
     if (passes < 2) passes = 2;                       // an even number of executed passes always exists (see os_schedule)
     const int shape = s.shape_knob ? s.shape_knob : (n <= ((size_t)3 << 19) ? 2 : 5);     // 4096-key tiles for small sorts, 8192-key tiles beyond (measured cross-over: 1.5M keys)
     const bool atomic_rank = s.rank_knob ? s.rank_knob == 2 : s.atomic_rank;
-#define GS4D_OS(T, I) (atomic_rank ? onesweep<T, I, true>(st, s, keys, vals, n, n_dev, passes, have_hist) : onesweep<T, I, false>(st, s, keys, vals, n, n_dev, passes, have_hist))
+#define GS4D_OS(T, I) (atomic_rank ? onesweep<T, I, true>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals) : onesweep<T, I, false>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals))
     switch (shape) {
     case 1: return GS4D_OS(256, 8);
     case 2: return GS4D_OS(512, 8);

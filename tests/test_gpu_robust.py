@@ -231,7 +231,11 @@ def test_compact_and_full_record_shadows(gs4d, oracle, monkeypatch):
     n, W, H = 20000, 640, 360
     pos4, q, sc, life, fade, vel, rgba = scenes.cube_params_4d(n, seed=21)
     rec = gs4d.build_records_4d(pos4, q, sc * 3.0, life * 20.0, fade, vel, rgba)
+    # R S S R^T comes out of the constructor symmetric only up to rounding for a general rotation (the teapot scenes' records ARE symmetric
+    # bit for bit: tests/test_oracle_golden.py); mirror the upper triangle so that this set qualifies for the compact shadow
     sig = rec[:, 8:].reshape(-1, 4, 4)
+    iu = np.triu_indices(4, 1)
+    sig[:, iu[1], iu[0]] = sig[:, iu[0], iu[1]]
     assert np.array_equal(sig, sig.transpose(0, 2, 1))
     cam = scenes.CAM_CUBE
     t = 20.0
