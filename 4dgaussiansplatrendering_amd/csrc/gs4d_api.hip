@@ -52,7 +52,7 @@ struct Buffer {
     // Provenance of a sort index: set when gs4d_sort_pairs has sorted exactly the keys and the identity index gs4d_keygen wrote for
     // `prov_data` — the contents are then "records of prov_data in ascending (depth key, record index)" for as long as `version`
     // still equals prov_ver, and a draw that binds it can take its blend order from the keys instead of reading it (tilelist.hip).
-    bool prov_valid = false; gs4d_buf prov_data = 0; uint64_t prov_data_ver = 0, prov_ver = 0; size_t prov_n = 0; int prov_bits = 32;
+    bool prov_valid = false; gs4d_buf prov_data = 0; uint64_t prov_data_ver = 0, prov_ver = 0; size_t prov_n = 0; int prov_bits = 32; uint32_t prov_span = 0xFFFFFFFFu;
     KeySrc prov_ks;
 };
 
@@ -66,6 +66,7 @@ struct DrawArgs {
     int lane = 0, fb = 0;          // where the draw ran
     bool v2 = false;               // unordered tile lists (tilelist.hip); false: instance-ordered lists (binning.hip)
     KeySrc ks; int keybits = 32;   // v2: where the blend order comes from
+    uint32_t key_span = 0xFFFFFFFFu; // ... and the host-proven largest blend key (the depth slabs divide [0, key_span])
     // the draw also executes the gs4d_keygen + gs4d_sort_pairs that were queued for it (first run only: a re-run finds the buffers sorted)
     bool fuse = false; gs4d_buf fuse_keys = 0, fuse_idx = 0; uint32_t fuse_span = 0xFFFFFFFFu;
     int blend_src = GS4D_SRC_ALPHA, blend_dst = GS4D_ONE_MINUS_SRC_ALPHA;       // glBlendFunc state at the draw
@@ -101,7 +102,7 @@ struct Lane {
     uint32_t* host_total = nullptr;     // pinned + mapped: [0..3] the binning total of the last draw, [4] the error word kernels raise
     uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
     gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
-    gs4d_buf kg_idx = 0, kg_data = 0; uint64_t kg_idx_ver = 0, kg_data_ver = 0; KeySrc kg_ks; int kg_bits = 32;   // ... the identity index it wrote beside them, and what the keys were computed from
+    gs4d_buf kg_idx = 0, kg_data = 0; uint64_t kg_idx_ver = 0, kg_data_ver = 0; KeySrc kg_ks; int kg_bits = 32; uint32_t kg_span = 0xFFFFFFFFu;   // ... the identity index it wrote beside them, and what the keys were computed from
     bool pending = false;              // the lane's last draw has not had its tile-list capacity validated yet
     bool discarded = false;            // ... and its image has been cleared since: validated (counted, learned from) but never re-run
     DrawArgs pending_args;
@@ -387,7 +388,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
-    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, c->slabs, a.keybits);
+    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, c->slabs, a.keybits, a.key_span);
     if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
     uint32_t* order_copy = nullptr;
     const bool regen = a.regen_order && !v2 && a.mode == GS4D_MODE_4D_SORTED && !a.quads;
@@ -499,7 +500,7 @@ int resolve_lane(gs4d_ctx* c, int li) {
             // the compositor's occupancy falls with the list capacity it is launched for: give capacity back when the lists stay short
             const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, L.host_total[5] + L.host_total[5] / 8u));
             if (!flags && fit < c->list_hint) { if (++c->shrink_votes >= 8) { c->list_hint = fit; c->shrink_votes = 0; } } else c->shrink_votes = 0;
-            if (!flags && c->slabs > 1u && L.host_total[5] * 3u < V2_MAX_LIST) { if (++c->unslab_votes >= 16) { c->slabs /= 2u; c->list_hint = V2_MAX_LIST; c->unslab_votes = 0; } } else c->unslab_votes = 0;
+            if (!flags && c->slabs > 1u && L.host_total[5] * 4u < c->list_hint) { if (++c->unslab_votes >= 16) { c->slabs /= 2u; c->unslab_votes = 0; } } else c->unslab_votes = 0;
         }
         if (!flags) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) { if (discarded) break; return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)"); }
@@ -507,19 +508,22 @@ int resolve_lane(gs4d_ctx* c, int li) {
         c->stat_entries = total;
         const bool was_v2 = L.pending_args.v2;     // an unordered draw kept no copy of its sort index: whatever path the re-run takes, it starts from the projection
         if (L.pending_args.v2 && (flags & 2u)) {
-            // A list longer than the compositor was launched for.
+            // A sub-list longer than the compositor was launched for.  What it can hold is a launch parameter (64 entries per lane register:
+            // v2_list_capacity) and costs registers and LDS; how long a tile's sub-lists are is set by the number of depth slabs.  Short
+            // lists (<= 512 on the tile): one slab, a capacity that fits.  Longer ones: enough slabs that the expected sub-list is ~384 and
+            // a capacity of 512 absorbs the imbalance of equal KEY ranges; then more capacity; then more slabs; when neither is left — all
+            // the keys of a tile equal, say — this is a scene for the instance-ordered path.  Estimates use the geometry THIS attempt ran with.
             const uint32_t longest = L.host_total[5], launched = L.tl.slabs;
-            if (longest <= V2_MAX_LIST) c->list_hint = std::max(c->list_hint, v2_list_capacity(longest + longest / 8u));      // a longer list capacity is enough
-            else {
-                // Longer than the compositor can hold: cut the lists into depth slabs (each sub-list is ordered by itself) if a few slabs
-                // bring the expected sub-list under the limit — slabs cost the compositor a sort per sub-list, so as few as possible —
-                // otherwise this is a scene for the instance-ordered path.  The estimate uses the geometry THIS attempt was launched with.
-                uint32_t want = launched;
-                while (want < V2_MAX_SLABS && (uint64_t)longest * launched > (uint64_t)want * (V2_MAX_LIST - V2_MAX_LIST / 4u) && (want * 2u) <= (1u << std::min(30, L.pending_args.keybits))) want *= 2u;
-                const bool helps = (uint64_t)longest * launched <= (uint64_t)want * V2_MAX_LIST && want > launched;
-                if (helps) { c->slabs = std::max(c->slabs, want); c->list_hint = V2_MAX_LIST; }
-                else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; L.pending_args.regen_order = true; }
-            }
+            const uint64_t whole = (uint64_t)longest * launched;
+            const uint32_t max_slabs = std::min<uint32_t>(V2_MAX_SLABS, 1u << std::min(30, L.pending_args.keybits));
+            const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, longest + longest / 8u));
+            uint32_t want = 1; while (want < max_slabs && whole > (uint64_t)want * 384u) want *= 2u;
+            if (launched == 1u && longest <= V2_MAX_LIST / 2u) c->list_hint = std::max(c->list_hint, fit);
+            else if (want > launched && want > c->slabs) { c->slabs = want; c->list_hint = std::max<uint32_t>(c->list_hint, V2_MAX_LIST / 2u); }
+            else if (longest <= V2_MAX_LIST && fit > c->list_hint) c->list_hint = fit;
+            else if (launched < max_slabs && launched * 2u > c->slabs) c->slabs = launched * 2u;
+            else if (launched < c->slabs || (longest <= V2_MAX_LIST && fit <= c->list_hint)) { /* another lane's draw has already raised the limits: run again with them */ }
+            else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; L.pending_args.regen_order = true; }
         }
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;
@@ -862,7 +866,7 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
         c->po.sorted = true;
         c->stat_depth_passes = (uint64_t)std::max(2, (Lq.depth_sort.hist_bits + 7) / 8);
         K->version++; V->version++;
-        V->prov_valid = true; V->prov_data = Lq.kg_data; V->prov_data_ver = Lq.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = Lq.kg_bits; V->prov_ks = Lq.kg_ks;
+        V->prov_valid = true; V->prov_data = Lq.kg_data; V->prov_data_ver = Lq.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = Lq.kg_bits; V->prov_ks = Lq.kg_ks; V->prov_span = Lq.kg_span;
         return GS4D_OK;
     }
     { int rc = flush_order(c); if (rc) return rc; rc = next_frame_if_drawn(c); if (rc) return rc; }
@@ -878,7 +882,7 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)V->d, n, nullptr, key_bits, have_hist));
     K->version++; V->version++;
     V->prov_valid = identity_payload;
-    if (identity_payload) { V->prov_data = L.kg_data; V->prov_data_ver = L.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = L.kg_bits; V->prov_ks = L.kg_ks; }
+    if (identity_payload) { V->prov_data = L.kg_data; V->prov_data_ver = L.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = L.kg_bits; V->prov_ks = L.kg_ks; V->prov_span = L.kg_span; }
     return GS4D_OK;
 }
 
@@ -933,7 +937,7 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     L.depth_sort.hist_bits = span < (1u << 8) ? 8 : span < (1u << 16) ? 16 : span < (1u << 24) ? 24 : 32;
     K->version++; I->version++;
     L.kg_buf = keys; L.kg_ver = K->version; L.kg_n = n;
-    L.kg_idx = idx; L.kg_idx_ver = I->version; L.kg_data = data; L.kg_data_ver = D->version; L.kg_bits = L.depth_sort.hist_bits;
+    L.kg_idx = idx; L.kg_idx_ver = I->version; L.kg_data = data; L.kg_data_ver = D->version; L.kg_bits = L.depth_sort.hist_bits; L.kg_span = span;
     L.kg_ks.mode = key_mode == GS4D_KEY_REF_INV_EUCLID ? KEYSRC_REF : KEYSRC_VIEWZ;
     L.kg_ks.t = t; L.kg_ks.camx = cam[0]; L.kg_ks.camy = cam[1]; L.kg_ks.camz = cam[2];
     L.kg_ks.vr0 = c->u.view[2]; L.kg_ks.vr1 = c->u.view[6]; L.kg_ks.vr2 = c->u.view[10]; L.kg_ks.vr3 = c->u.view[14];
@@ -976,11 +980,12 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
         if (data && (a.quads || a.mode == GS4D_MODE_4D_DIRECT || a.mode == GS4D_MODE_2D)) {
             nkeys = std::min(a.instances, data->bytes / (a.quads ? 288 : a.mode == GS4D_MODE_2D ? 48 : 96));
             a.ks = KeySrc(); a.keybits = 1; while (a.keybits < 32 && ((size_t)1 << a.keybits) < nkeys) ++a.keybits;
+            a.key_span = nkeys ? (uint32_t)(nkeys - 1) : 0u;
             ok = nkeys > 0;
         } else if (data && a.mode == GS4D_MODE_4D_SORTED) {
             const Buffer* ob = getbuf(c, a.order);
             if (ob && ob->prov_valid && ob->version == ob->prov_ver && a.data == ob->prov_data && data->version == ob->prov_data_ver && a.instances == ob->prov_n && data->bytes / 96 == ob->prov_n) {
-                a.ks = ob->prov_ks; a.keybits = ob->prov_bits; ok = true;
+                a.ks = ob->prov_ks; a.keybits = ob->prov_bits; a.key_span = ob->prov_span; ok = true;
             }
         }
         if (ok && (nkeys > V2_MAX_RECORDS || (a.mode == GS4D_MODE_4D_SORTED && a.instances > V2_MAX_RECORDS) || (size_t)c->tiles_x * c->tiles_y > 256u * 1024u)) ok = false;   // tilelist.hip's entry format
@@ -998,10 +1003,10 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
         const Buffer* pd = getbuf(c, a.data);
         bool mine = a.mode == GS4D_MODE_4D_SORTED && !a.quads && c->po.sorted && c->po.idx == a.order && c->po.data == a.data && c->po.lane == c->cur
                  && pd && a.instances == c->po.n && pd->bytes / 96 == c->po.n;
-        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, c->slabs, a.keybits)) a.v2 = false;
+        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, c->slabs, a.keybits, a.key_span)) a.v2 = false;
         if (mine) {
             // on the ordered path too: the projection writes the keys, the sort follows it, the binning reads the sorted index
-            if (!a.v2) { a.ks = lane(c).kg_ks; a.keybits = lane(c).kg_bits; }
+            if (!a.v2) { a.ks = lane(c).kg_ks; a.keybits = lane(c).kg_bits; a.key_span = lane(c).kg_span; }
             a.fuse = true; a.fuse_keys = c->po.keys; a.fuse_idx = c->po.idx; a.fuse_span = c->po.span; c->po.keygen = c->po.sorted = false; c->stat_fused++;
         }
         else { int rc2 = flush_order(c); if (rc2) return rc2; }

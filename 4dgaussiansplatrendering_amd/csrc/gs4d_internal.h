@@ -117,7 +117,7 @@ struct TileCount {                               // hist == nullptr: the ordered
     float* keys_out = nullptr; uint32_t* idx_out = nullptr; uint32_t* ghist = nullptr; uint32_t span = 0xFFFFFFFFu; uint32_t* err = nullptr;
 };
 constexpr uint32_t V2_MAX_LIST = 1024;           // longest list the compositor sorts in LDS (beyond ~1000 entries per tile its LDS footprint costs more occupancy than the ordered path's two sort passes cost time).  Longer per-tile lists are cut into depth slabs (below); beyond V2_MAX_SLABS a draw uses the ordered path
-constexpr uint32_t V2_MAX_SLABS = 4;            // a tile's list is kept as `slabs` sub-lists by the top bits of the blend key: far slab first, each ordered by itself in the compositor
+constexpr uint32_t V2_MAX_SLABS = 64;           // a tile's list is kept as `slabs` sub-lists by equal ranges of the blend key: far slab first, each ordered by itself in the compositor (one wave lane holds a sub-list's table entry: <= 64)
 constexpr int SEG_THREADS = 512;                 // workgroup size of the kernels that walk a segment of records (k_preprocess<.., true>, k_bucket_scatter)
 // list capacities the compositor is instantiated for (64 entries per lane-register): the smallest one >= n
 inline uint32_t v2_list_capacity(uint32_t n) {
@@ -128,12 +128,14 @@ inline uint32_t v2_list_capacity(uint32_t n) {
 constexpr uint32_t V2_MAX_RECORDS = 1u << 24;    // an entry carries (tile / nb) in the top byte of its record word
 struct TileLists {
     uint32_t* hist = nullptr; size_t hist_cap = 0;            // [nb][rows] counts, turned in place into the slot of every (segment, bucket) run inside its bucket
-    uint32_t* bbase = nullptr; uint32_t* btot = nullptr; uint32_t* tstart = nullptr; uint32_t* tcnt = nullptr; size_t tiles_cap = 0, nb_cap = 0;   // [nb + 1] bucket starts, [nb] bucket totals; per tile: first entry, entries
+    uint32_t* bbase = nullptr; uint32_t* btot = nullptr; uint32_t* tstart = nullptr; uint32_t* tcnt = nullptr; size_t tiles_cap = 0, nb_cap = 0, slabs_cap = 0;   // [nb + 1] bucket starts, [nb] bucket totals; per tile: first entry, entries
     uint32_t* skey = nullptr; size_t skey_cap = 0;
+    uint32_t counters = 0;                                    // LDS counters of k_bucket_tiles: (tiles per bucket) * slabs
     uint32_t nb = 0, rows = 0, seg = 0, slabs = 1, slab_shift = 0;   // geometry of the current draw (tile_lists_plan): slab of an entry = min(slabs - 1, key >> slab_shift)
 };
 // false: this frame / record count cannot use the unordered path (more than 256 * 1024 tiles, or 2^24 records)
-bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits);
+// key_span: host-proven largest blend key (the slabs divide [0, key_span] evenly)
+bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span = 0xFFFFFFFFu);
 hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_t nrecords);
 void tile_lists_free(TileLists& t);
 // total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list,

@@ -26,6 +26,7 @@
 // (larger capacity, longer lists, or the ordered path).
 #include "gs4d_internal.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace gs4d {
 
@@ -153,24 +154,28 @@ __global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter(const uint2* __r
     }
 }
 
-// Bucket b -> the lists of its tiles (tile = h * nb + b, h < 256): count per list, scan, place.  A tile's list is kept as `slabs`
-// sub-lists by the top bits of the blend key (far slab first): counter = h * slabs + slab.  A thread keeps up to 8 entries in registers
-// (all loads in flight at once); a bucket of up to 8192 entries is read once, a longer one in rounds of 8192, twice.
-constexpr int BT_THREADS = 1024, BT_ITEMS = 8, BT_COUNTERS = 256 * (int)V2_MAX_SLABS;
-__global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift,
+// Bucket b -> the lists of its tiles (tile = h * nb + b, h < tpb <= 256): count per list, scan, place.  A tile's list is kept as `slabs`
+// sub-lists by depth (far slab first; slab of an entry = min(slabs - 1, key >> slab_shift)): counter = h * slabs + slab.  The compositor
+// orders every sub-list by itself in LDS, so `slabs` is what bounds the list it has to hold, not the tile's whole list (10^7 splats at
+// 1080p put up to 4 400 entries on a tile).  The counters live in dynamic LDS (tpb * slabs of them, at most BT_MAX_COUNTERS).
+// A thread keeps up to 8 entries in registers (all loads in flight at once); a bucket of up to 8192 entries is read once, a longer one
+// in rounds of 8192, twice.
+constexpr int BT_THREADS = 1024, BT_ITEMS = 8;
+constexpr uint32_t BT_MAX_COUNTERS = 16384;
+__global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift, uint32_t nc,
                                                              uint32_t* __restrict__ tstart, uint32_t* __restrict__ tcnt, uint2* __restrict__ entries,
                                                              uint32_t* __restrict__ total, uint32_t hint) {
-    __shared__ uint32_t cnt[BT_COUNTERS];
+    extern __shared__ uint32_t cnt[];                      // [nc]
     __shared__ uint32_t ws[BT_THREADS / 64];
     if (total[1] & 1u) return;                             // capacity overflow (set by k_bucket_scan); bit 1 is raised HERE by other workgroups and must not stop this one
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
     const uint32_t lo = bbase[b], hi = bbase[b + 1];
-    const uint32_t nc = 256u * slabs, sl = (uint32_t)__ffs((int)slabs) - 1u;      // counters in use; log2(slabs)
+    const uint32_t sl = (uint32_t)__ffs((int)slabs) - 1u;  // log2(slabs)
     constexpr uint32_t ROUND = BT_THREADS * BT_ITEMS;
     const bool single = hi - lo <= ROUND;
     for (uint32_t k = tid; k < nc; k += BT_THREADS) cnt[k] = 0u;
     __syncthreads();
-    auto counter_of = [&](const uint2& e) { return ((e.y >> 24) << sl) | min(slabs - 1u, e.x >> slab_shift); };
+    auto counter_of = [&](const uint2& e) { return min(nc - 1u, ((e.y >> 24) << sl) | min(slabs - 1u, e.x >> slab_shift)); };      // (the outer min only keeps a corrupt entry inside LDS)
     uint2 e[BT_ITEMS];
     for (uint32_t r0 = lo; r0 < hi; r0 += ROUND) {
 #pragma unroll
@@ -179,11 +184,10 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
         for (int j = 0; j < BT_ITEMS; ++j) if (e[j].y != 0xFFFFFFFFu) atomicAdd(&cnt[counter_of(e[j])], 1u);
     }
     __syncthreads();
-    // exclusive scan of the nc counters (4 per thread at most), the tile table, the longest list
-    constexpr int CPT = BT_COUNTERS / BT_THREADS;
-    uint32_t c[CPT], sum = 0, mx = 0;
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) { const uint32_t q = tid * CPT + k; c[k] = q < nc ? cnt[q] : 0u; sum += c[k]; mx = max(mx, c[k]); }
+    // exclusive scan of the nc counters (thread t owns counters [t * cpt, (t + 1) * cpt)), the tile table, the longest sub-list
+    const uint32_t cpt = (nc + BT_THREADS - 1u) / BT_THREADS, q0 = tid * cpt;
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t k = 0; k < cpt; ++k) { const uint32_t q = q0 + k; const uint32_t c = q < nc ? cnt[q] : 0u; sum += c; mx = max(mx, c); }
     uint32_t inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
@@ -195,14 +199,14 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
 #pragma unroll
     for (int k = 0; k < BT_THREADS / 64; ++k) if ((unsigned)k < w) base += ws[k];
     uint32_t run = lo + base + inc - sum;
-#pragma unroll
-    for (int k = 0; k < CPT; ++k) {
-        const uint32_t q = tid * CPT + k;
+    for (uint32_t k = 0; k < cpt; ++k) {
+        const uint32_t q = q0 + k;
         if (q < nc) {
-            cnt[q] = run;                                  // from here on: the list's running position
+            const uint32_t c = cnt[q];
+            cnt[q] = run;                                  // from here on: the sub-list's running position (only this thread touches counter q in this phase)
             const uint32_t tile = (q >> sl) * nb + b;
-            if (tile < ntiles) { tstart[(size_t)tile * slabs + (q & (slabs - 1u))] = run; tcnt[(size_t)tile * slabs + (q & (slabs - 1u))] = c[k]; }
-            run += c[k];
+            if (tile < ntiles) { tstart[(size_t)tile * slabs + (q & (slabs - 1u))] = run; tcnt[(size_t)tile * slabs + (q & (slabs - 1u))] = c; }
+            run += c;
         }
     }
     if (lane == 0u && mx) { atomicMax(&total[4], mx); if (mx > hint) atomicOr(&total[1], 2u); }
@@ -221,11 +225,15 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
     // (the entry count, the longest list and the flags reach the host through the compositing kernel that follows: no hand-off here)
 }
 
-bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits) {
+bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span) {
     if (nrecords == 0 || nrecords > V2_MAX_RECORDS) return false;
     // buckets: enough that tile / nb < 256, and about 8192 entries each (k_bucket_tiles reads a bucket of that size once) at ~1.4 entries per record
     uint32_t nb = 64;
     while (((size_t)nb * 256 < ntiles || (size_t)nb * 8192 < nrecords + nrecords / 2) && nb < 1024) nb *= 2;
+    if (const char* ev = getenv("GS4D_NB")) {            // tuning knob: number of buckets (a power of two, 64..1024), subject to the entry format
+        const uint32_t v = (uint32_t)atoi(ev);
+        if (v >= 64 && v <= 1024 && (v & (v - 1)) == 0 && (size_t)v * 256 >= ntiles) nb = v;
+    }
     if ((size_t)nb * 256 < ntiles) return false;
     // segments of >= 2048 records (at 10^6 records 4096 left the projection with 245 workgroups = 8 waves per CU in flight: 44.6 us; longer
     // segments mean longer runs per bucket and a smaller count matrix), at most 1024 of them (k_bucket_scan keeps a bucket's counts in registers)
@@ -236,7 +244,15 @@ bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slab
     if (slabs > V2_MAX_SLABS) slabs = V2_MAX_SLABS;
     int sl = 0; while ((1u << sl) < slabs) ++sl;
     if (keybits < sl) return false;
-    t.nb = nb; t.rows = (uint32_t)rows; t.seg = (uint32_t)seg; t.slabs = 1u << sl; t.slab_shift = (uint32_t)(keybits - sl);
+    // the slabs divide [0, key_span] (the host-proven range of the blend keys; 2^keybits - 1 where nothing tighter is known) into equal
+    // key ranges: the smallest shift that leaves fewer than `slabs` values — between slabs / 2 and slabs of the sub-lists are then in use
+    const uint32_t top = keybits >= 32 ? 0xFFFFFFFFu : ((1u << keybits) - 1u);
+    const uint32_t span = std::min(key_span, top);
+    uint32_t shift = 0; while (shift < 32u && (span >> shift) >= (1u << sl)) ++shift;
+    if (sl == 0) shift = 31u;                            // one slab: whatever the key, slab 0 (min(0, ...))
+    const uint32_t tpb = (uint32_t)((ntiles + nb - 1) / nb);
+    if (((size_t)tpb << sl) > BT_MAX_COUNTERS) return false;      // k_bucket_tiles keeps one counter per (tile of the bucket, slab) in LDS
+    t.nb = nb; t.rows = (uint32_t)rows; t.seg = (uint32_t)seg; t.slabs = 1u << sl; t.slab_shift = std::min(shift, 31u); t.counters = tpb << sl;
     return true;
 }
 
@@ -249,13 +265,13 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
         if ((e = hipMalloc(&t.hist, hist_words * 8)) != hipSuccess) return e;      // [nb][rows] counts, then [rows][nb] run slots
         t.hist_cap = hist_words;
     }
-    if (t.tiles_cap < ntiles || t.nb_cap < t.nb) {
+    if (t.tiles_cap < ntiles || t.nb_cap < t.nb || t.slabs_cap < t.slabs) {
         if (t.bbase) { (void)hipStreamSynchronize(st); (void)hipFree(t.bbase); }
         t.bbase = t.btot = t.tstart = t.tcnt = nullptr;
-        const size_t nt = std::max(ntiles, t.tiles_cap), nbc = std::max<size_t>(t.nb, t.nb_cap);
-        if ((e = hipMalloc(&t.bbase, (2 * nbc + 1 + 2 * nt * V2_MAX_SLABS) * 4)) != hipSuccess) return e;     // the tile table holds V2_MAX_SLABS sub-lists per tile
-        t.btot = t.bbase + nbc + 1; t.tstart = t.btot + nbc; t.tcnt = t.tstart + nt * V2_MAX_SLABS;
-        t.tiles_cap = nt; t.nb_cap = nbc;
+        const size_t nt = std::max(ntiles, t.tiles_cap), nbc = std::max<size_t>(t.nb, t.nb_cap), sc = std::max<size_t>(std::max<size_t>(t.slabs, t.slabs_cap), 4);
+        if ((e = hipMalloc(&t.bbase, (2 * nbc + 1 + 2 * nt * sc) * 4)) != hipSuccess) return e;     // the tile table holds `slabs` sub-lists per tile
+        t.btot = t.bbase + nbc + 1; t.tstart = t.btot + nbc; t.tcnt = t.tstart + nt * sc;
+        t.tiles_cap = nt; t.nb_cap = nbc; t.slabs_cap = sc;
     }
     if (t.skey_cap < nrecords) {
         if (t.skey) { (void)hipStreamSynchronize(st); (void)hipFree(t.skey); }
@@ -284,7 +300,7 @@ hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rect
 }
 
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint) {
-    k_bucket_tiles<<<dim3(t.nb), dim3(BT_THREADS), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, t.tstart, t.tcnt, entries, total, hint);
+    k_bucket_tiles<<<dim3(t.nb), dim3(BT_THREADS), t.counters * 4u, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, t.counters, t.tstart, t.tcnt, entries, total, hint);
     return hipGetLastError();
 }
 

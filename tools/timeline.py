@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Steady-state timeline of the three streams from a rocprofv3 kernel trace (csv).
+"""Steady-state timeline of the frame lanes' streams from a rocprofv3 kernel trace (csv).
 
 usage: tools/timeline.py <dir with *_kernel_trace.csv> [first_frame] [frames]
 Prints, for a window of frames, each kernel's start offset, duration and queue; then per-queue busy time and the fraction of the
@@ -17,7 +17,7 @@ for r in csv.DictReader(open(f)):
     name = name.split("<")[0]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?")))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if r[2] == "k_keygen"]
+starts = [i for i, r in enumerate(rows) if r[2] in ("k_keygen", "k_project_count")]      # a frame begins with its key generation: a kernel of its own, or the projection that does it
 if len(starts) < first + nfr + 1:
     first = max(0, len(starts) - nfr - 1)
 t0, t1 = rows[starts[first]][0], rows[starts[first + nfr]][0]
@@ -45,3 +45,13 @@ agg = collections.defaultdict(lambda: [0, 0])
 for s, e, n, q in win:
     agg[n][0] += 1; agg[n][1] += e - s
 print("per kernel (launches/frame, us/frame):", {n: (round(c / nfr, 1), round(t / 1e3 / nfr, 1)) for n, (c, t) in agg.items()})
+# idle time between consecutive kernels of one queue (a frame lane is one stream, normally one hardware queue): launch gaps
+gaps = collections.defaultdict(list)
+lastend = {}
+for s, e, n, q in win:
+    if q in lastend and s > lastend[q]:
+        gaps[q].append((s - lastend[q]) / 1e3)
+    lastend[q] = max(e, lastend.get(q, 0))
+for q, g in gaps.items():
+    g2 = sorted(g)
+    print(f"queue {q}: {len(g)} gaps, total {sum(g) / nfr:.1f} us/frame, median {g2[len(g2) // 2]:.1f} us, max {g2[-1]:.1f} us")
