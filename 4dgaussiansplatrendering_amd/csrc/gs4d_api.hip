@@ -46,6 +46,7 @@ struct Buffer {
     unsigned tail_mask = 0;        // lanes whose other kernels (key generation) have read it since that write (their tail event does)
     uint64_t touch = 0;            // context op counter at the last device-side use (host writes compare it with the last full sync)
     bool alive = false;
+    bool ptr_exposed = false;      // gs4d_buffer_device_ptr has handed the storage's address out: the storage may never be exchanged (see Lane::spare)
     // The caller announced (gs4d_buffer_invalidate) that work on ITS stream rewrites the buffer: every lane that uses it afterwards first
     // waits for an event recorded on that stream at the first such use (the caller has queued the writes by then: that is the contract).
     hipEvent_t ev_fill = nullptr; unsigned fill_mask = 0; bool fill_recorded = false;
@@ -65,6 +66,8 @@ struct DrawArgs {
     bool fb_was_clear = false;     // framebuffer state the composite of this draw must start from (kept for a re-run)
     int lane = 0, fb = 0;          // where the draw ran
     bool v2 = false;               // unordered tile lists (tilelist.hip); false: instance-ordered lists (binning.hip)
+    bool sorted = false;           // v2: lists ordered by the bucket sort and walked (long lists) instead of ordered by the compositing wave
+    int bs_items = 8;              // ... with this many entries per thread
     KeySrc ks; int keybits = 32;   // v2: where the blend order comes from
     uint32_t key_span = 0xFFFFFFFFu; // ... and the host-proven largest blend key (the depth slabs divide [0, key_span])
     // the draw also executes the gs4d_keygen + gs4d_sort_pairs that were queued for it (first run only: a re-run finds the buffers sorted)
@@ -103,6 +106,14 @@ struct Lane {
     uint32_t* host_total_dev = nullptr; // the same memory as the device sees it
     gs4d_buf kg_buf = 0; uint64_t kg_ver = 0; size_t kg_n = 0;   // key buffer whose digit histograms k_keygen left for the next sort
     gs4d_buf kg_idx = 0, kg_data = 0; uint64_t kg_idx_ver = 0, kg_data_ver = 0; KeySrc kg_ks; int kg_bits = 32; uint32_t kg_span = 0xFFFFFFFFu;   // ... the identity index it wrote beside them, and what the keys were computed from
+    // Storage renaming for per-frame key / index buffers.  A buffer object is a NAME; its device storage is the library's.  gs4d_keygen
+    // overwrites its two output buffers entirely, so when their storage is still being written or read by ANOTHER lane's frame (an
+    // application with one key / index pair for all frames: the reference's layout, Scenes.h m_key_buf / m_values_buf) the new frame
+    // does not wait for it: the buffers exchange their storage with this lane's spare pair and the earlier frame finishes on what is now
+    // the spare.  When storage leaves a buffer everything that uses it has already been queued (API calls are sequential): an event is
+    // recorded right then on every lane that wrote or still reads it, and the lane that takes the storage back later waits for exactly
+    // those events — not for the lanes' tail events, which by then cover later frames as well and would chain the lanes to each other.
+    struct Spare { void* d = nullptr; size_t bytes = 0; uint64_t touch = 0; unsigned wait_mask = 0; hipEvent_t ev[MAX_LANES] = { nullptr }; } spare[2];
     bool pending = false;              // the lane's last draw has not had its tile-list capacity validated yet
     bool discarded = false;            // ... and its image has been cleared since: validated (counted, learned from) but never re-run
     DrawArgs pending_args;
@@ -145,9 +156,17 @@ struct gs4d_ctx {
              int key_mode = 0; uint32_t bias = 0, span = 0xFFFFFFFFu; float view[16] = { 0 }; } po;
     int blend_src = GS4D_SRC_ALPHA, blend_dst = GS4D_ONE_MINUS_SRC_ALPHA;     // glBlendFunc state (Application.cpp:137-138, 150)
     bool defer_order = true;           // GS4D_FUSE_KEYGEN=0 switches the deferral off (test hook)
-    uint64_t stat_fused = 0;
-    int shrink_votes = 0, unslab_votes = 0;
-    uint32_t slabs = 1;                // depth slabs per tile list (tilelist.hip): doubled when a list outgrows V2_MAX_LIST, given back when the lists stay short
+    uint64_t stat_fused = 0, stat_renamed = 0;
+    bool rename_storage = true;        // GS4D_RENAME=0 switches the storage exchange off (test hook)
+    int shrink_votes = 0, unsort_votes = 0;
+    uint32_t slabs = 1;                // depth slabs per tile list (tilelist.hip): GS4D_SLABS sets it (the mechanism stays tested; the library itself sends long lists to the bucket sort)
+    // Three ways to get a tile's list into blend order, by how long the lists are: (1) short (<= 512 entries): unordered lists, ordered by the
+    // wave that composites the tile (k_composite_v2); (2) long: the bucket-wide LDS sort (k_bucket_sort) and a compositor that walks ordered
+    // lists of any length; (3) buckets beyond what that sort holds, or a blend order that is not a key the library knows: the
+    // instance-ordered path (binning.hip).  The context remembers what the scene needed last (validated per draw on the device).
+    bool sorted_lists = false;         // (2) is in use
+    int bs_items = 8;                  // entries per thread the bucket sort is launched with (8 or 16: 8 192 / 16 384 entries per bucket)
+    uint64_t stat_sorted_draws = 0;
     uint32_t list_hint = 256;          // LDS list capacity the compositor is launched with (64 << k); grows on demand, validated per draw on the device
     uint64_t stat_v2_draws = 0, stat_longest = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
@@ -343,20 +362,24 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     uint2* tmp = (uint2*)L.pair_keys;              // the lane's entry storage holds 16 bytes per slot: [0, cap) bucket order, [cap, 2 cap) tile order
     uint2* entries = tmp + L.pair_cap;
+    int recbits = 1; while (recbits < 32 && ((size_t)1 << recbits) < nrecords) ++recbits;
     {
         StageTimer t(c, GS4D_T_BINNING);
         HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
         const uint32_t* fused_keys = nullptr;
         if (a.fuse) { Buffer* K = getbuf(c, a.fuse_keys); if (K) fused_keys = (const uint32_t*)K->d; }      // the projection wrote the keys there and nowhere else
-        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, fused_keys, a.ks.bias, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world));
-        HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
+        // what a segment is expected to emit (from the last validated draw, with a margin) picks the staging area; a segment that outgrows it writes directly
+        const size_t per_seg = c->stat_entries ? (size_t)((c->stat_entries + c->stat_entries / 4) / std::max<uint32_t>(1u, L.tl.rows)) + 64 : 0;
+        HIPCHK(c, launch_bucket_scatter_staged(L.s, L.tl, L.rects, fused_keys, a.ks.bias, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world, per_seg));
+        if (a.sorted) HIPCHK(c, launch_bucket_sort(L.s, L.tl, ntiles, L.bin.total, tmp, entries, a.keybits, recbits, a.bs_items > 8 ? 16384 : 8192));
+        else HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
     }
     c->stat_tile_passes = 0;
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
-        int recbits = 1; while (recbits < 32 && ((size_t)1 << recbits) < nrecords) ++recbits;
-        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem,
-                                      c->list_hint, a.keybits, recbits, L.tl.slabs));
+        if (a.sorted) HIPCHK(c, launch_composite_walk(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem));
+        else HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem,
+                                           c->list_hint, a.keybits, recbits, L.tl.slabs));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event (the compositor's first workgroup wrote them)
     return GS4D_OK;
@@ -388,7 +411,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
-    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, c->slabs, a.keybits, a.key_span);
+    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, a.sorted ? 1u : c->slabs, a.keybits, a.key_span);
     if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
     uint32_t* order_copy = nullptr;
     const bool regen = a.regen_order && !v2 && a.mode == GS4D_MODE_4D_SORTED && !a.quads;
@@ -499,31 +522,32 @@ int resolve_lane(gs4d_ctx* c, int li) {
             c->stat_longest = L.host_total[5];
             // the compositor's occupancy falls with the list capacity it is launched for: give capacity back when the lists stay short
             const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, L.host_total[5] + L.host_total[5] / 8u));
-            if (!flags && fit < c->list_hint) { if (++c->shrink_votes >= 8) { c->list_hint = fit; c->shrink_votes = 0; } } else c->shrink_votes = 0;
-            if (!flags && c->slabs > 1u && L.host_total[5] * 4u < c->list_hint) { if (++c->unslab_votes >= 16) { c->slabs /= 2u; c->unslab_votes = 0; } } else c->unslab_votes = 0;
+            if (!L.pending_args.sorted) { if (!flags && fit < c->list_hint) { if (++c->shrink_votes >= 8) { c->list_hint = fit; c->shrink_votes = 0; } } else c->shrink_votes = 0; }
+            // the bucket sort is for long lists: when they have been short for a while the compositing wave orders them itself again
+            if (L.pending_args.sorted && !flags && L.host_total[5] * 2u < V2_MAX_LIST / 2u) { if (++c->unsort_votes >= 16) { c->sorted_lists = false; c->bs_items = 8; c->unsort_votes = 0; } } else c->unsort_votes = 0;
         }
         if (!flags) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) { if (discarded) break; return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)"); }
         if (discarded) c->stat_aborted_discarded++; else c->stat_reruns++;
         c->stat_entries = total;
         const bool was_v2 = L.pending_args.v2;     // an unordered draw kept no copy of its sort index: whatever path the re-run takes, it starts from the projection
-        if (L.pending_args.v2 && (flags & 2u)) {
-            // A sub-list longer than the compositor was launched for.  What it can hold is a launch parameter (64 entries per lane register:
-            // v2_list_capacity) and costs registers and LDS; how long a tile's sub-lists are is set by the number of depth slabs.  Short
-            // lists (<= 512 on the tile): one slab, a capacity that fits.  Longer ones: enough slabs that the expected sub-list is ~384 and
-            // a capacity of 512 absorbs the imbalance of equal KEY ranges; then more capacity; then more slabs; when neither is left — all
-            // the keys of a tile equal, say — this is a scene for the instance-ordered path.  Estimates use the geometry THIS attempt ran with.
-            const uint32_t longest = L.host_total[5], launched = L.tl.slabs;
-            const uint64_t whole = (uint64_t)longest * launched;
-            const uint32_t max_slabs = std::min<uint32_t>(V2_MAX_SLABS, 1u << std::min(30, L.pending_args.keybits));
+        if (L.pending_args.v2 && (flags & 4u)) {
+            // A bucket larger than the bucket sort was launched for (8 192 entries at 8 per thread, 16 384 at 16): once more with 16, else
+            // this is a scene for the instance-ordered path.
+            if (L.pending_args.bs_items < 16) { c->bs_items = 16; L.pending_args.bs_items = 16; }
+            else { c->long_lists = true; c->ordered_draws = 0; c->sorted_lists = false; L.pending_args.v2 = false; L.pending_args.sorted = false; L.pending_args.regen_order = true; }
+        } else if (L.pending_args.v2 && (flags & 2u)) {
+            // A (sub-)list longer than the compositing wave was launched for.  What it can hold is a launch parameter (64 entries per lane
+            // register: v2_list_capacity) that costs registers and LDS.  Up to 512 entries: a capacity that fits.  Longer lists: order them
+            // in the bucket sort instead.  (With depth slabs forced by GS4D_SLABS: up to 1024 per sub-list, else the instance-ordered path.)
+            const uint32_t longest = L.host_total[5];
             const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, longest + longest / 8u));
-            uint32_t want = 1; while (want < max_slabs && whole > (uint64_t)want * 384u) want *= 2u;
-            if (launched == 1u && longest <= V2_MAX_LIST / 2u) c->list_hint = std::max(c->list_hint, fit);
-            else if (want > launched && want > c->slabs) { c->slabs = want; c->list_hint = std::max<uint32_t>(c->list_hint, V2_MAX_LIST / 2u); }
-            else if (longest <= V2_MAX_LIST && fit > c->list_hint) c->list_hint = fit;
-            else if (launched < max_slabs && launched * 2u > c->slabs) c->slabs = launched * 2u;
-            else if (launched < c->slabs || (longest <= V2_MAX_LIST && fit <= c->list_hint)) { /* another lane's draw has already raised the limits: run again with them */ }
-            else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; L.pending_args.regen_order = true; }
+            if (L.tl.slabs > 1u) {
+                if (longest <= V2_MAX_LIST) c->list_hint = std::max(c->list_hint, fit);
+                else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; L.pending_args.regen_order = true; }
+            }
+            else if (longest <= V2_MAX_LIST / 2u) c->list_hint = std::max(c->list_hint, fit);
+            else { c->sorted_lists = true; L.pending_args.sorted = true; L.pending_args.bs_items = c->bs_items; c->stat_sorted_draws++; }
         }
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;
@@ -628,7 +652,9 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     for (int i = 0; i < 4; ++i) c->u.view[5 * i] = c->u.proj[5 * i] = 1.0f;
     if (const char* ev = getenv("GS4D_LANES")) { const int v = atoi(ev); if (v >= 1 && v <= MAX_LANES) c->nlanes = v; }     // tuning knob
     if (const char* ev = getenv("GS4D_FUSE_KEYGEN")) c->defer_order = atoi(ev) != 0;                                       // test hook: 0 = launch key generation and sort at once
-    if (const char* ev = getenv("GS4D_DRAW_PATH")) { if (!strcmp(ev, "ordered")) c->path_pref = 1; }                         // test hook: instance-ordered tile lists for every draw
+    if (const char* ev = getenv("GS4D_DRAW_PATH")) { if (!strcmp(ev, "ordered")) c->path_pref = 1; }
+    if (const char* ev = getenv("GS4D_RENAME")) c->rename_storage = atoi(ev) != 0;
+    if (const char* ev = getenv("GS4D_SLABS")) { const int v = atoi(ev); if (v >= 1 && v <= (int)V2_MAX_SLABS) { c->slabs = 1; while ((int)c->slabs < v) c->slabs *= 2u; } }      // test hook: depth slabs (a power of two)                         // test hook: instance-ordered tile lists for every draw
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
     for (int i = 0; i < c->nlanes; ++i) {
         Lane& L = c->lanes[i];
@@ -668,6 +694,7 @@ void gs4d_destroy(gs4d_ctx* c) {
         if (L.line_verts) (void)hipFree(L.line_verts);
         if (L.order_copy) (void)hipFree(L.order_copy);
         if (L.regen_keys) (void)hipFree(L.regen_keys);
+        for (auto& sp : L.spare) { if (sp.d) (void)hipFree(sp.d); for (hipEvent_t e : sp.ev) if (e) (void)hipEventDestroy(e); }
         if (L.proj) (void)hipFree(L.proj);
         if (L.rects) (void)hipFree(L.rects);
         if (L.pair_keys) (void)hipFree(L.pair_keys);
@@ -768,6 +795,7 @@ int gs4d_buffer_device_ptr(gs4d_ctx* c, gs4d_buf b, void** dptr, size_t* bytes) 
     if (!B) return fail(c, GS4D_E_INVALID, "buffer_device_ptr: bad buffer name");
     if (dptr) *dptr = B->d;
     if (bytes) *bytes = B->bytes;
+    B->ptr_exposed = true;                          // the address is the caller's to keep: this storage stays with this name
     B->version++;                                   // the caller may write through the pointer
     return GS4D_OK;
 }
@@ -896,6 +924,44 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     if (n == 0) return GS4D_OK;
     { int rc = flush_order(c); if (rc) return rc; rc = next_frame_if_drawn(c); if (rc) return rc; }
     int rc = ensure_soa(c, *D); if (rc) return rc;
+    {
+        // both outputs are overwritten entirely: if another lane's frame still uses their storage, take this lane's spare storage instead of waiting (Lane::spare)
+        Lane& Lr = lane(c);
+        auto busy_elsewhere = [&](const Buffer& B) { return (B.wr_lane >= 0 && B.wr_lane != c->cur) || ((B.rd_mask | B.tail_mask) & ~(1u << c->cur)) != 0u; };
+        auto renamable = [&](const Buffer& B) { return !B.ptr_exposed && B.bytes == n * 4 && B.fill_mask == 0u && B.touch > c->synced; };
+        if (c->rename_storage && c->nlanes > 1 && K != I && K != D && I != D && renamable(*K) && renamable(*I) && (busy_elsewhere(*K) || busy_elsewhere(*I))) {
+            Buffer* out[2] = { K, I };
+            bool ok = true;
+            for (int k = 0; k < 2 && ok; ++k) {
+                Lane::Spare& sp = Lr.spare[k];
+                if (sp.d && sp.bytes != n * 4) {            // another size than last time: the old spare is given back once nothing can still use it
+                    if (sp.touch > c->synced) { rc = sync_all(c); if (rc) return rc; }
+                    (void)hipFree(sp.d); sp = Lane::Spare();
+                }
+                if (!sp.d) { if (hipMalloc(&sp.d, n * 4) != hipSuccess) { (void)hipGetLastError(); sp.d = nullptr; ok = false; } else sp.bytes = n * 4; }
+            }
+            if (ok) {
+                for (int k = 0; k < 2; ++k) {
+                    Buffer& B = *out[k]; Lane::Spare& sp = Lr.spare[k];
+                    // the storage coming in: after what used it when it left its buffer (waits capture the events as recorded now)
+                    for (int r = 0; r < c->nlanes; ++r) if (((sp.wait_mask >> r) & 1u) && r != c->cur) HIPCHK(c, hipStreamWaitEvent(Lr.s, sp.ev[r], 0));
+                    // the storage going out: mark, on every other lane that uses it, the point up to which it does
+                    unsigned users = B.rd_mask | B.tail_mask | (B.wr_lane >= 0 ? 1u << B.wr_lane : 0u);
+                    users &= ~(1u << c->cur);                // this lane's own earlier uses are ordered by its stream
+                    for (int r = 0; r < c->nlanes; ++r) if ((users >> r) & 1u) {
+                        if (!sp.ev[r]) HIPCHK(c, hipEventCreateWithFlags(&sp.ev[r], hipEventDisableTiming));
+                        HIPCHK(c, hipEventRecord(sp.ev[r], c->lanes[r].s));
+                    }
+                    sp.wait_mask = users;
+                    std::swap(B.d, sp.d);
+                    std::swap(B.touch, sp.touch);
+                    B.wr_lane = -1; B.ordered_mask = 0; B.rd_mask = 0; B.tail_mask = 0;      // nothing but the waits above stands between this lane and the storage
+                    B.touch = ++c->ops;                      // (kernels may still be running on it: a host access has to synchronise)
+                }
+                c->stat_renamed++;
+            }
+        }
+    }
     { rc = lane_access(c, *D, false); if (rc) return rc; D->tail_mask |= 1u << c->cur; rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *I, true); if (rc) return rc; }
     Lane& L = lane(c);
     // A proven lower bound of every key (1 / farthest possible distance, from the bounding box of the records) is subtracted inside
@@ -995,6 +1061,8 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
             if (++c->ordered_draws >= 64 && c->stat_entries / (tiles ? tiles : 1) <= V2_MAX_LIST / 8) c->long_lists = false; else ok = false;
         }
         a.v2 = ok;
+        a.sorted = ok && c->sorted_lists && c->slabs == 1u;
+        a.bs_items = c->bs_items;
     }
     a.fuse = false;
     if (c->po.keygen) {
@@ -1003,7 +1071,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
         const Buffer* pd = getbuf(c, a.data);
         bool mine = a.mode == GS4D_MODE_4D_SORTED && !a.quads && c->po.sorted && c->po.idx == a.order && c->po.data == a.data && c->po.lane == c->cur
                  && pd && a.instances == c->po.n && pd->bytes / 96 == c->po.n;
-        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, c->slabs, a.keybits, a.key_span)) a.v2 = false;
+        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, a.sorted ? 1u : c->slabs, a.keybits, a.key_span)) a.v2 = false;
         if (mine) {
             // on the ordered path too: the projection writes the keys, the sort follows it, the binning reads the sorted index
             if (!a.v2) { a.ks = lane(c).kg_ks; a.keybits = lane(c).kg_bits; a.key_span = lane(c).kg_span; }
@@ -1016,7 +1084,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     rc = run_draw(c, a, true);
     a.fuse = false;                    // a re-run of this draw finds the keys written and the sort queued
     if (rc) { L.proj_n = before; return rc; }
-    if (L.proj_n) { L.pending = true; L.pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; if (a.v2) c->stat_v2_draws++; }   // proj_n != 0 <=> raster work was enqueued
+    if (L.proj_n) { L.pending = true; L.pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; if (a.v2) c->stat_v2_draws++; if (a.v2 && a.sorted) c->stat_sorted_draws++; }   // proj_n != 0 <=> raster work was enqueued
     else L.proj_n = before;
     if (c->profiling) { if (c->prof_frame < gs4d_ctx::PROF_FRAMES && c->prof_tick % (uint64_t)c->prof_every == 0) c->prof_frame++; c->prof_tick++; }
     return GS4D_OK;
@@ -1275,8 +1343,8 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     if (!c || !stats) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
-    stats[4] = c->stat_depth_passes; stats[5] = c->stat_tile_passes; stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
+    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = ((uint64_t)c->tiles_x * c->tiles_y) | (c->stat_sorted_draws << 32);
+    stats[4] = c->stat_depth_passes; stats[5] = (c->stat_tile_passes & 0xFFFFFFFFull) | (c->stat_renamed << 32); stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }
 

@@ -94,18 +94,19 @@ def test_equal_depth_keys_blend_in_index_order(gs4d, oracle, monkeypatch):
     assert linf(other, eimg) > 1e-2
 
 
-def test_long_lists_grow_the_compositor_then_depth_slabs_then_fall_back(gs4d, oracle, monkeypatch):
-    """Hundreds, then thousands, of splats on the same pixels.  The list-building kernels report the longest list; the draw is re-run with
-    a larger LDS list capacity in the compositor, then with the lists cut into depth slabs, and — when slabs cannot help because the
-    keys are all equal — on the instance-ordered path.  Every time the same picture."""
+def test_long_lists_grow_the_compositor_then_the_bucket_sort_then_fall_back(gs4d, oracle, monkeypatch):
+    """Hundreds, then thousands, of splats on the same pixels.  The list-building kernels report the longest list.  Up to 512 entries
+    the compositing wave orders a tile's list itself (re-run with a larger LDS capacity when needed); longer lists are ordered by the
+    bucket-wide sort and walked — also when every key is the same (the bucket sort breaks ties on the record index); a bucket beyond what
+    that sort holds (16 384 entries) sends the draw to the instance-ordered path.  Every time the same picture."""
     W, H = 256, 256
     cam = ((0.0, 0.0, 60.0), (0.0, 0.0, -1.0))
     view, proj = cam_mats(gs4d, cam, W, H)
     ctx = _ctx(gs4d, W, H, monkeypatch)
     seen = []
-    for n, spread in ((700, 0.1), (700, 0.1), (2500, 0.1), (3000, 0.0), (120, 0.1)):
+    for n, spread in ((400, 0.1), (400, 0.1), (2500, 0.1), (3000, 0.0), (20000, 0.1), (120, 0.1)):
         pos, q, sc, rgba = scenes.cube_params(n, seed=50 + n)
-        rgba[:, 3] *= 0.05
+        rgba[:, 3] *= 0.05 if n < 10000 else 0.004
         pos[:, 0:2] = 0.0                                                     # all on the view axis: one spot of the image; spread 0: one depth, equal keys
         rec = gs4d.build_records_3d(pos * spread, q, sc * 1.5, rgba)
         img, perm, _, st = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
@@ -114,18 +115,87 @@ def test_long_lists_grow_the_compositor_then_depth_slabs_then_fall_back(gs4d, or
         assert linf(img, eimg) <= TOL
         assert np.abs(eimg - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.05
         seen.append(st)
-    # frame 1: unordered, re-run with a longer list capacity; frame 2: unordered, no re-run
-    assert seen[0]["unordered_draws"] == 1 and seen[0]["reruns"] == 1 and 256 < seen[0]["longest_list"] <= 700 and seen[0]["tile_sort_passes"] == 0
-    assert seen[1]["unordered_draws"] == 2 and seen[1]["reruns"] == 1 and seen[1]["tile_sort_passes"] == 0
-    # frame 3: 2500 entries on a tile, distinct depths: cut into depth slabs if that brings every sub-list under the compositor's limit,
-    # else the instance-ordered path — either way after at least one re-run
-    assert seen[2]["reruns"] > 1
-    if seen[2]["tile_sort_passes"] == 0:
-        assert seen[2]["longest_list"] <= 1024
-    # frame 4: 3000 entries with ONE key: no slab boundary separates them -> the instance-ordered path; frame 5 stays there
-    assert seen[3]["tile_sort_passes"] >= 2
-    assert seen[4]["unordered_draws"] == seen[3]["unordered_draws"] and seen[4]["reruns"] == seen[3]["reruns"] and seen[4]["tile_sort_passes"] >= 2
+    # frame 1: unordered, re-run with a longer list capacity in the compositing wave; frame 2: the same, no re-run
+    assert seen[0]["unordered_draws"] == 1 and seen[0]["reruns"] == 1 and 256 < seen[0]["longest_list"] <= 400 and seen[0]["tile_sort_passes"] == 0 and seen[0]["bucket_sorted_draws"] == 0
+    assert seen[1]["unordered_draws"] == 2 and seen[1]["reruns"] == 1 and seen[1]["bucket_sorted_draws"] == 0
+    # frame 3: 2500 entries on a tile: one re-run, on the bucket sort; frame 4: 3000 entries with ONE key: the bucket sort again, at once (ties go by record index)
+    assert seen[2]["reruns"] == 2 and seen[2]["bucket_sorted_draws"] == 1 and seen[2]["tile_sort_passes"] == 0 and 2000 < seen[2]["longest_list"] <= 2500
+    assert seen[3]["reruns"] == 2 and seen[3]["bucket_sorted_draws"] == 2 and seen[3]["tile_sort_passes"] == 0
+    # frame 5: 20000 entries on one tile = in one bucket: 8 per thread, then 16 per thread, then the instance-ordered path; frame 6 stays there
+    assert seen[4]["reruns"] == 4 and seen[4]["tile_sort_passes"] >= 2
+    assert seen[5]["unordered_draws"] == seen[4]["unordered_draws"] and seen[5]["reruns"] == seen[4]["reruns"] and seen[5]["tile_sort_passes"] >= 2
     ctx.close()
+
+
+@pytest.mark.parametrize("slabs", [4, 32])
+def test_depth_slabs(gs4d, oracle, monkeypatch, slabs):
+    """GS4D_SLABS: a tile's list kept as sub-lists by equal ranges of the blend key, each ordered by itself in the compositing wave, far
+    sub-list first.  (The library itself sends long lists to the bucket sort; the mechanism is kept, and kept tested.)  Same frame as the
+    instance-ordered path, bit for bit; sub-lists beyond 1024 entries send the draw to the instance-ordered path."""
+    n, W, H = 60000, 640, 360
+    pos, q, sc, rgba = scenes.cube_params(n, seed=61)
+    rgba[:, 3] *= 0.3
+    rec = gs4d.build_records_3d(pos * 0.25, q, sc * 4.0, rgba)
+    cam = ((150.0, 100.0, -60.0), (-0.77, -0.57, 0.27))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_SLABS=slabs)
+    img, perm, _, st = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
+    ctx.close()
+    assert np.array_equal(perm, eperm) and linf(img, eimg) <= TOL
+    assert st["unordered_draws"] >= 1 and st["tile_sort_passes"] == 0 and st["bucket_sorted_draws"] == 0
+    ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_DRAW_PATH="ordered")
+    img_o, _, _, _ = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
+    ctx.close()
+    assert np.array_equal(img, img_o)
+    # 5000 splats of one depth on one spot: no key range separates them
+    pos2, q2, sc2, rgba2 = scenes.cube_params(5000, seed=62)
+    rgba2[:, 3] *= 0.02
+    pos2[:, :] = 0.0
+    rec2 = gs4d.build_records_3d(pos2, q2, sc2 * 1.5, rgba2)
+    cam2 = ((0.0, 0.0, 60.0), (0.0, 0.0, -1.0))
+    view2, proj2 = cam_mats(gs4d, cam2, W, H)
+    ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_SLABS=slabs)
+    img2, perm2, _, st2 = _sorted_frame(ctx, gs4d, rec2, cam2, view2, proj2)
+    ctx.close()
+    eimg2, eperm2, _ = oracle.render_4d(rec2, True, 0.0, 0.0, cam2[0], view2, proj2, W, H)
+    assert np.array_equal(perm2, eperm2) and linf(img2, eimg2) <= TOL and st2["tile_sort_passes"] >= 2
+
+
+def test_bucket_sorted_lists_match_the_other_paths(gs4d, oracle, monkeypatch):
+    """A dense cloud (lists of a few thousand entries on the busiest tiles): the draw ends on the bucket-sorted path, with the same frame as
+    the instance-ordered path bit for bit (same records, same order, same chunking) — for the reference's key, for keys that tie, and for
+    instance-index order (4D-direct)."""
+    n, W, H = 300000, 640, 360
+    pos, q, sc, rgba = scenes.cube_params(n, seed=63)
+    rgba[:, 3] *= 0.2
+    pos = np.repeat(pos[: n // 2] * 0.15, 2, 0)                 # every position twice: keys tie in pairs
+    rec = gs4d.build_records_3d(pos, q, sc * 2.0, rgba)
+    cam = ((150.0, 100.0, -60.0), (-0.77, -0.57, 0.27))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H, nthreads=16)
+    imgs = {}
+    for path in ("auto", "ordered"):
+        ctx = _ctx(gs4d, W, H, monkeypatch, **({"GS4D_DRAW_PATH": "ordered"} if path == "ordered" else {}))
+        img, perm, _, st = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
+        assert np.array_equal(perm, eperm)
+        assert linf(img, eimg) <= TOL
+        if path == "auto":
+            assert st["bucket_sorted_draws"] >= 1 and st["tile_sort_passes"] == 0 and st["longest_list"] > 1024
+            # instance-index order on the same path
+            db = ctx.buffer(rec)
+            ctx.clear()
+            ctx.set_mode(gs4d.MODE_4D_DIRECT)
+            ctx.bind(1, db)
+            ctx.draw_instanced(n)
+            direct = ctx.read_pixels()
+            assert ctx.stats()["bucket_sorted_draws"] > st["bucket_sorted_draws"]
+            eproj = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H)
+            edirect = oracle.composite(eproj, None, oracle.MODE_4D, W, H, oracle.clear_image(W, H), nthreads=16)
+            assert linf(direct, edirect) <= TOL
+        ctx.close()
+        imgs[path] = img
+    assert np.array_equal(imgs["auto"], imgs["ordered"])
 
 
 @pytest.mark.parametrize("path", ["auto", "ordered"])
