@@ -114,6 +114,7 @@ struct Lane {
     // recorded right then on every lane that wrote or still reads it, and the lane that takes the storage back later waits for exactly
     // those events — not for the lanes' tail events, which by then cover later frames as well and would chain the lanes to each other.
     struct Spare { void* d = nullptr; size_t bytes = 0; uint64_t touch = 0; unsigned wait_mask = 0; hipEvent_t ev[MAX_LANES] = { nullptr }; } spare[2];
+    int bs_launched = 8;               // entries per thread the lane's last bucket sort ran with
     bool pending = false;              // the lane's last draw has not had its tile-list capacity validated yet
     bool discarded = false;            // ... and its image has been cleared since: validated (counted, learned from) but never re-run
     DrawArgs pending_args;
@@ -371,7 +372,11 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
         // what a segment is expected to emit (from the last validated draw, with a margin) picks the staging area; a segment that outgrows it writes directly
         const size_t per_seg = c->stat_entries ? (size_t)((c->stat_entries + c->stat_entries / 4) / std::max<uint32_t>(1u, L.tl.rows)) + 64 : 0;
         HIPCHK(c, launch_bucket_scatter_staged(L.s, L.tl, L.rects, fused_keys, a.ks.bias, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world, per_seg));
-        if (a.sorted) HIPCHK(c, launch_bucket_sort(L.s, L.tl, ntiles, L.bin.total, tmp, entries, a.keybits, recbits, a.bs_items > 8 ? 16384 : 8192));
+        if (a.sorted) {
+            // 8 entries per thread (8192 per bucket, two workgroups per CU) unless the scene is known to fill its buckets beyond ~6500
+            L.bs_launched = (a.bs_items > 8 || c->stat_entries / std::max<uint32_t>(1u, L.tl.nb) > 6500u) ? 16 : 8;
+            HIPCHK(c, launch_bucket_sort(L.s, L.tl, ntiles, L.bin.total, tmp, entries, a.keybits, recbits, L.bs_launched > 8 ? 16384 : 8192));
+        }
         else HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
     }
     c->stat_tile_passes = 0;
@@ -411,7 +416,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
-    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, a.sorted ? 1u : c->slabs, a.keybits, a.key_span);
+    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, a.sorted ? 1u : c->slabs, a.keybits, a.key_span, a.sorted ? (size_t)c->stat_entries : 0);
     if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
     uint32_t* order_copy = nullptr;
     const bool regen = a.regen_order && !v2 && a.mode == GS4D_MODE_4D_SORTED && !a.quads;
@@ -534,7 +539,7 @@ int resolve_lane(gs4d_ctx* c, int li) {
         if (L.pending_args.v2 && (flags & 4u)) {
             // A bucket larger than the bucket sort was launched for (8 192 entries at 8 per thread, 16 384 at 16): once more with 16, else
             // this is a scene for the instance-ordered path.
-            if (L.pending_args.bs_items < 16) { c->bs_items = 16; L.pending_args.bs_items = 16; }
+            if (L.bs_launched < 16) { c->bs_items = 16; L.pending_args.bs_items = 16; }
             else { c->long_lists = true; c->ordered_draws = 0; c->sorted_lists = false; L.pending_args.v2 = false; L.pending_args.sorted = false; L.pending_args.regen_order = true; }
         } else if (L.pending_args.v2 && (flags & 2u)) {
             // A (sub-)list longer than the compositing wave was launched for.  What it can hold is a launch parameter (64 entries per lane
@@ -1071,7 +1076,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
         const Buffer* pd = getbuf(c, a.data);
         bool mine = a.mode == GS4D_MODE_4D_SORTED && !a.quads && c->po.sorted && c->po.idx == a.order && c->po.data == a.data && c->po.lane == c->cur
                  && pd && a.instances == c->po.n && pd->bytes / 96 == c->po.n;
-        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, a.sorted ? 1u : c->slabs, a.keybits, a.key_span)) a.v2 = false;
+        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, a.sorted ? 1u : c->slabs, a.keybits, a.key_span, a.sorted ? (size_t)c->stat_entries : 0)) a.v2 = false;
         if (mine) {
             // on the ordered path too: the projection writes the keys, the sort follows it, the binning reads the sorted index
             if (!a.v2) { a.ks = lane(c).kg_ks; a.keybits = lane(c).kg_bits; a.key_span = lane(c).kg_span; }

@@ -135,7 +135,7 @@ struct TileLists {
 };
 // false: this frame / record count cannot use the unordered path (more than 256 * 1024 tiles, or 2^24 records)
 // key_span: host-proven largest blend key (the slabs divide [0, key_span] evenly)
-bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span = 0xFFFFFFFFu);
+bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span = 0xFFFFFFFFu, size_t expect_entries = 0);
 hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_t nrecords);
 void tile_lists_free(TileLists& t);
 // total[0] entries (saturated), [1] abort flags (1: more entries than `cap`, 2: a list longer than `hint`), [2..3] 64-bit entry count, [4] longest list,

@@ -451,11 +451,13 @@ __global__ __launch_bounds__(BS_THREADS) void k_bucket_sort(const uint2* __restr
     for (int j = 0; j < ITEMS; ++j) { const uint32_t i = base + j * 64u + lane; if (i < E) entries[lo + i] = make_uint2(bs.k[j], bs.r[j] & 0x00FFFFFFu); }
 }
 
-bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span) {
+bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span, size_t expect_entries) {
     if (nrecords == 0 || nrecords > V2_MAX_RECORDS) return false;
-    // buckets: enough that tile / nb < 256, and about 8192 entries each (k_bucket_tiles reads a bucket of that size once) at ~1.4 entries per record
+    // buckets: enough that tile / nb < 256, and about 8192 entries each (k_bucket_tiles reads a bucket of that size once) at ~1.4 entries per
+    // record — or, when the scene's entry count is known from an earlier draw (long lists: the bucket sort holds 8192 / 16384 entries), ~6000 each
     uint32_t nb = 64;
-    while (((size_t)nb * 256 < ntiles || (size_t)nb * 8192 < nrecords + nrecords / 2) && nb < 1024) nb *= 2;
+    const size_t est = expect_entries ? expect_entries + expect_entries / 3 : nrecords + nrecords / 2;
+    while (((size_t)nb * 256 < ntiles || (size_t)nb * 8192 < est) && nb < 1024) nb *= 2;
     if (const char* ev = getenv("GS4D_NB")) {            // tuning knob: number of buckets (a power of two, 64..1024), subject to the entry format
         const uint32_t v = (uint32_t)atoi(ev);
         if (v >= 64 && v <= 1024 && (v & (v - 1)) == 0 && (size_t)v * 256 >= ntiles) nb = v;

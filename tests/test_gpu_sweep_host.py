@@ -61,6 +61,72 @@ def test_cpp_sweep_host_frames_equal_the_python_driven_render(gs4d, tmp_path):
     assert f"{crc:08x}" == line["frames_crc32"]
 
 
+@pytest.mark.gpu
+def test_cpp_sweep_tile_row_sharding_entry(gs4d, tmp_path):
+    """gs4d_sweep --shard-tiles: the timed entry of BASELINE.json configs[4]'s shape (ONE frame, tile rows dealt to the ranks, bands gathered
+    on rank 0).  With a communicator of one rank the band is the whole frame: it must equal the Python-driven render of the same records,
+    bit for bit; the band bookkeeping for N ranks is restated on the CPU in test_band_layout_of_the_tile_row_sharding."""
+    if not os.path.isfile(SWEEP):
+        pytest.fail("host/gs4d_sweep is not built (make sweep)")
+    n, W, H = 40000, 640, 360
+    out = subprocess.run([SWEEP, "--gpus", "1", "--shard-tiles", "--splats", str(n), "--frames", "3", "--sweeps", "2", "--warmup", "1",
+                          "--width", str(W), "--height", str(H), "--dump", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["mode"] == "shard_tiles" and line["n_gpus"] == 1 and line["ms_per_frame"] > 0 and line["tile_list_entries_rank0"] > 0
+    theirs = np.fromfile(os.path.join(tmp_path, "frame_tiles.rgba8"), np.uint8)
+    assert f"{zlib.crc32(theirs.tobytes()):08x}" == line["image_crc32"]
+    # the program writes records.bin only in the frame-sharded mode: regenerate through a 1-frame run of that mode
+    out2 = subprocess.run([SWEEP, "--gpus", "1", "--splats", str(n), "--frames", "1", "--sweeps", "1", "--warmup", "0", "--width", str(W), "--height", str(H),
+                           "--dump", str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    rec = np.fromfile(os.path.join(tmp_path, "records.bin"), np.float32).reshape(n, 24)
+    cam = ((551.58, 350.43, -184.33), (-0.774978, -0.570354, 0.272222))
+    view = gs4d.look_at(cam[0], cam[1])
+    proj = gs4d.perspective(60.0, W, H, 0.1, 5000.0)
+    ctx = gs4d.Context(W, H)
+    db, kb, ib, ob = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * W * H)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.bind(2, db)
+    t = 25.0
+    ctx.clear()
+    ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+    ctx.keygen(db, t, cam[0], kb, ib, n)
+    ctx.sort_pairs(kb, ib, n)
+    ctx.bind(1, ib)
+    ctx.draw_instanced(n)
+    ctx.read_pixels_rgba8_device(ctx.device_ptr(ob)[0], W * H * 4)
+    ctx.finish()
+    mine = ctx.read(ob, np.uint8, W * H * 4)
+    ctx.close()
+    assert np.array_equal(mine, theirs)
+
+
+def test_band_layout_of_the_tile_row_sharding():
+    """gs4d_sweep --shard-tiles: rank r's band is its tile rows ty = r, r + N, ... in ascending ty, 8 pixel rows each (the last may be
+    shorter); rank 0 stores the bands one after another and reassembles the frame tile row by tile row.  Same bookkeeping as
+    sharding.band_pixel_rows / assemble_bands."""
+    import importlib
+    sharding = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
+    for H, N in [(1080, 8), (2160, 8), (360, 3), (13, 2), (8, 4)]:
+        tiles_y = (H + 7) // 8
+        band_rows = [0] * N
+        for ty in range(tiles_y):
+            band_rows[ty % N] += min(8, H - ty * 8)
+        for r in range(N):
+            assert band_rows[r] == len(sharding.band_pixel_rows(r, N, H))
+        cur = [0] * N
+        seen = []
+        for ty in range(tiles_y):
+            r = ty % N
+            rows = sharding.band_pixel_rows(r, N, H)[cur[r]:cur[r] + min(8, H - ty * 8)]
+            assert rows == list(range(ty * 8, min(H, ty * 8 + 8)))
+            cur[r] += len(rows)
+            seen += rows
+        assert seen == list(range(H))
+
+
 def test_sweep_schedule_matches_the_sharding_helpers():
     """gs4d_sweep.cpp: rank r renders frames r, r + N, ...; slot p of its batch b holds its frame b * G + p; every rank presents
     ceil(F / N) times.  The same mapping as sharding.frames_for_rank / bench.py's N > 1 leg."""
