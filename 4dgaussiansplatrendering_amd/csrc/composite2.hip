@@ -131,45 +131,6 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     }
 }
 
-// The walker: the tile's list arrives ORDERED (k_bucket_sort, tilelist.hip) — any length — and is blended from its end, 64 entries at a time.
-template <bool PREMULT_C>
-__global__ __launch_bounds__(64) void k_composite_walk(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
-                                                       const uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, int tiles_x, int W, int H, int fb_is_clear, float4 clear, float4* __restrict__ fb) {
-    __shared__ __attribute__((aligned(16))) float4 stage[64 * 3];
-    __shared__ uint32_t pmask[64 * 2];
-    uint32_t tile;
-    const bool real = composite_tile(blockIdx.x, tiles_x, (H + TILE - 1) / TILE, tile);
-    const uint32_t lane = threadIdx.x;
-    if (blockIdx.x == 0u && lane == 0u) { total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = total[4]; total_host[1] = total[1]; }
-    if (total[1] || !real) return;                          // aborted draw (capacity, or a bucket the sort cannot hold): the host re-runs it
-    const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE;
-    const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
-    const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
-    float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
-    const uint32_t start = tstart[tile], E = tcnt[tile];
-    for (uint32_t hi = E; hi > 0u;) {
-        const uint32_t c = min(64u, hi);
-        const uint32_t rec = lane < c ? entries[start + hi - 1u - lane].y : 0u;       // lane s holds list entry hi-1-s : s = 0 is the front-most of the chunk
-        composite_chunk<PREMULT_C>(proj, rec, c, lane, tx0, ty0, fx, fy, stage, pmask, 0, T, Cr, Cg, Cb, A);
-        hi -= c;
-        if (__ballot(T > 0.0f) == 0ull) break;              // exact: every remaining contribution is multiplied by T == 0
-    }
-    if (px < W && py < H) {
-        const size_t o = (size_t)py * W + px;
-        const float4 d = fb_is_clear ? clear : fb[o];
-        fb[o] = make_float4(Cr + T * d.x, Cg + T * d.y, Cb + T * d.z, A + T * d.w);
-    }
-}
-
-hipError_t launch_composite_walk(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
-                                 int premult_c, int fb_is_clear, const float clear[4], float4* fb) {
-    const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
-    const dim3 grid(composite_grid(tiles_x, tiles_y));
-    if (premult_c) k_composite_walk<true><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb);
-    else k_composite_walk<false><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb);
-    return hipGetLastError();
-}
-
 template <bool PREMULT_C>
 static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int W, int H,
                             int fb_is_clear, float4 c, float4* fb, int kp, int rp, uint32_t slabs) {

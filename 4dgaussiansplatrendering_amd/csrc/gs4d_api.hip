@@ -66,8 +66,6 @@ struct DrawArgs {
     bool fb_was_clear = false;     // framebuffer state the composite of this draw must start from (kept for a re-run)
     int lane = 0, fb = 0;          // where the draw ran
     bool v2 = false;               // unordered tile lists (tilelist.hip); false: instance-ordered lists (binning.hip)
-    bool sorted = false;           // v2: lists ordered by the bucket sort and walked (long lists) instead of ordered by the compositing wave
-    int bs_items = 8;              // ... with this many entries per thread
     KeySrc ks; int keybits = 32;   // v2: where the blend order comes from
     uint32_t key_span = 0xFFFFFFFFu; // ... and the host-proven largest blend key (the depth slabs divide [0, key_span])
     // the draw also executes the gs4d_keygen + gs4d_sort_pairs that were queued for it (first run only: a re-run finds the buffers sorted)
@@ -114,7 +112,6 @@ struct Lane {
     // recorded right then on every lane that wrote or still reads it, and the lane that takes the storage back later waits for exactly
     // those events — not for the lanes' tail events, which by then cover later frames as well and would chain the lanes to each other.
     struct Spare { void* d = nullptr; size_t bytes = 0; uint64_t touch = 0; unsigned wait_mask = 0; hipEvent_t ev[MAX_LANES] = { nullptr }; } spare[2];
-    int bs_launched = 8;               // entries per thread the lane's last bucket sort ran with
     bool pending = false;              // the lane's last draw has not had its tile-list capacity validated yet
     bool discarded = false;            // ... and its image has been cleared since: validated (counted, learned from) but never re-run
     DrawArgs pending_args;
@@ -159,15 +156,12 @@ struct gs4d_ctx {
     bool defer_order = true;           // GS4D_FUSE_KEYGEN=0 switches the deferral off (test hook)
     uint64_t stat_fused = 0, stat_renamed = 0;
     bool rename_storage = true;        // GS4D_RENAME=0 switches the storage exchange off (test hook)
-    int shrink_votes = 0, unsort_votes = 0;
-    uint32_t slabs = 1;                // depth slabs per tile list (tilelist.hip): GS4D_SLABS sets it (the mechanism stays tested; the library itself sends long lists to the bucket sort)
-    // Three ways to get a tile's list into blend order, by how long the lists are: (1) short (<= 512 entries): unordered lists, ordered by the
-    // wave that composites the tile (k_composite_v2); (2) long: the bucket-wide LDS sort (k_bucket_sort) and a compositor that walks ordered
-    // lists of any length; (3) buckets beyond what that sort holds, or a blend order that is not a key the library knows: the
-    // instance-ordered path (binning.hip).  The context remembers what the scene needed last (validated per draw on the device).
-    bool sorted_lists = false;         // (2) is in use
-    int bs_items = 8;                  // entries per thread the bucket sort is launched with (8 or 16: 8 192 / 16 384 entries per bucket)
-    uint64_t stat_sorted_draws = 0;
+    int shrink_votes = 0;
+    // Two ways to get a tile's list into blend order.  Lists of up to V2_MAX_LIST entries: built unordered, ordered by the wave that
+    // composites the tile (k_composite_v2).  Longer lists, or a blend order that is not a key the library knows: the instance-ordered path
+    // (binning.hip) — at 10^7 splats (1500 entries on the average non-empty tile) it is the faster one by 7-17 % against every way of
+    // keeping such lists on the unordered path that round 3 built and measured: depth slabs of the lists, a bucket-wide LDS sort.
+    uint32_t slabs = 1;                // depth slabs per tile list (tilelist.hip): only GS4D_SLABS sets it — an experiment knob whose mechanism stays tested
     uint32_t list_hint = 256;          // LDS list capacity the compositor is launched with (64 << k); grows on demand, validated per draw on the device
     uint64_t stat_v2_draws = 0, stat_longest = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
@@ -369,22 +363,14 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
         HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
         const uint32_t* fused_keys = nullptr;
         if (a.fuse) { Buffer* K = getbuf(c, a.fuse_keys); if (K) fused_keys = (const uint32_t*)K->d; }      // the projection wrote the keys there and nowhere else
-        // what a segment is expected to emit (from the last validated draw, with a margin) picks the staging area; a segment that outgrows it writes directly
-        const size_t per_seg = c->stat_entries ? (size_t)((c->stat_entries + c->stat_entries / 4) / std::max<uint32_t>(1u, L.tl.rows)) + 64 : 0;
-        HIPCHK(c, launch_bucket_scatter_staged(L.s, L.tl, L.rects, fused_keys, a.ks.bias, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world, per_seg));
-        if (a.sorted) {
-            // 8 entries per thread (8192 per bucket, two workgroups per CU) unless the scene is known to fill its buckets beyond ~6500
-            L.bs_launched = (a.bs_items > 8 || c->stat_entries / std::max<uint32_t>(1u, L.tl.nb) > 6500u) ? 16 : 8;
-            HIPCHK(c, launch_bucket_sort(L.s, L.tl, ntiles, L.bin.total, tmp, entries, a.keybits, recbits, L.bs_launched > 8 ? 16384 : 8192));
-        }
-        else HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
+        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, fused_keys, a.ks.bias, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world));
+        HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
     }
     c->stat_tile_passes = 0;
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
-        if (a.sorted) HIPCHK(c, launch_composite_walk(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem));
-        else HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem,
-                                           c->list_hint, a.keybits, recbits, L.tl.slabs));
+        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem,
+                                      c->list_hint, a.keybits, recbits, L.tl.slabs));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event (the compositor's first workgroup wrote them)
     return GS4D_OK;
@@ -416,7 +402,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     if (a.instances >= 0xFFFFFFFFull || nrec >= 0xFFFFFFFFull) return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32-1 instances");
 
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
-    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, a.sorted ? 1u : c->slabs, a.keybits, a.key_span, a.sorted ? (size_t)c->stat_entries : 0);
+    bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, c->slabs, a.keybits, a.key_span);
     if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
     uint32_t* order_copy = nullptr;
     const bool regen = a.regen_order && !v2 && a.mode == GS4D_MODE_4D_SORTED && !a.quads;
@@ -527,32 +513,20 @@ int resolve_lane(gs4d_ctx* c, int li) {
             c->stat_longest = L.host_total[5];
             // the compositor's occupancy falls with the list capacity it is launched for: give capacity back when the lists stay short
             const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, L.host_total[5] + L.host_total[5] / 8u));
-            if (!L.pending_args.sorted) { if (!flags && fit < c->list_hint) { if (++c->shrink_votes >= 8) { c->list_hint = fit; c->shrink_votes = 0; } } else c->shrink_votes = 0; }
-            // the bucket sort is for long lists: when they have been short for a while the compositing wave orders them itself again
-            if (L.pending_args.sorted && !flags && L.host_total[5] * 2u < V2_MAX_LIST / 2u) { if (++c->unsort_votes >= 16) { c->sorted_lists = false; c->bs_items = 8; c->unsort_votes = 0; } } else c->unsort_votes = 0;
+            if (!flags && fit < c->list_hint) { if (++c->shrink_votes >= 8) { c->list_hint = fit; c->shrink_votes = 0; } } else c->shrink_votes = 0;
         }
         if (!flags) { c->stat_entries = total; break; }
         if (total >= 0xFFFFFFF0ull) { if (discarded) break; return fail(c, GS4D_E_UNSUPPORTED, "draw: more than 2^32 tile-list entries (splats cover too many tiles)"); }
         if (discarded) c->stat_aborted_discarded++; else c->stat_reruns++;
         c->stat_entries = total;
         const bool was_v2 = L.pending_args.v2;     // an unordered draw kept no copy of its sort index: whatever path the re-run takes, it starts from the projection
-        if (L.pending_args.v2 && (flags & 4u)) {
-            // A bucket larger than the bucket sort was launched for (8 192 entries at 8 per thread, 16 384 at 16): once more with 16, else
-            // this is a scene for the instance-ordered path.
-            if (L.bs_launched < 16) { c->bs_items = 16; L.pending_args.bs_items = 16; }
-            else { c->long_lists = true; c->ordered_draws = 0; c->sorted_lists = false; L.pending_args.v2 = false; L.pending_args.sorted = false; L.pending_args.regen_order = true; }
-        } else if (L.pending_args.v2 && (flags & 2u)) {
+        if (L.pending_args.v2 && (flags & 2u)) {
             // A (sub-)list longer than the compositing wave was launched for.  What it can hold is a launch parameter (64 entries per lane
-            // register: v2_list_capacity) that costs registers and LDS.  Up to 512 entries: a capacity that fits.  Longer lists: order them
-            // in the bucket sort instead.  (With depth slabs forced by GS4D_SLABS: up to 1024 per sub-list, else the instance-ordered path.)
+            // register: v2_list_capacity) that costs registers and LDS.  Up to V2_MAX_LIST entries: a capacity that fits.  Longer: this is a
+            // scene for the instance-ordered path (the re-run regenerates the order the draw was issued with: DrawArgs::regen_order).
             const uint32_t longest = L.host_total[5];
-            const uint32_t fit = v2_list_capacity(std::min<uint32_t>(V2_MAX_LIST, longest + longest / 8u));
-            if (L.tl.slabs > 1u) {
-                if (longest <= V2_MAX_LIST) c->list_hint = std::max(c->list_hint, fit);
-                else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; L.pending_args.regen_order = true; }
-            }
-            else if (longest <= V2_MAX_LIST / 2u) c->list_hint = std::max(c->list_hint, fit);
-            else { c->sorted_lists = true; L.pending_args.sorted = true; L.pending_args.bs_items = c->bs_items; c->stat_sorted_draws++; }
+            if (longest <= V2_MAX_LIST) c->list_hint = std::max(c->list_hint, v2_list_capacity(longest + longest / 8u));
+            else { c->long_lists = true; c->ordered_draws = 0; L.pending_args.v2 = false; L.pending_args.regen_order = true; }
         }
         int rc = ensure_pairs(c, L, (size_t)(total + total / 8 + 1024));
         if (rc) return rc;
@@ -1066,8 +1040,6 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
             if (++c->ordered_draws >= 64 && c->stat_entries / (tiles ? tiles : 1) <= V2_MAX_LIST / 8) c->long_lists = false; else ok = false;
         }
         a.v2 = ok;
-        a.sorted = ok && c->sorted_lists && c->slabs == 1u;
-        a.bs_items = c->bs_items;
     }
     a.fuse = false;
     if (c->po.keygen) {
@@ -1076,7 +1048,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
         const Buffer* pd = getbuf(c, a.data);
         bool mine = a.mode == GS4D_MODE_4D_SORTED && !a.quads && c->po.sorted && c->po.idx == a.order && c->po.data == a.data && c->po.lane == c->cur
                  && pd && a.instances == c->po.n && pd->bytes / 96 == c->po.n;
-        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, a.sorted ? 1u : c->slabs, a.keybits, a.key_span, a.sorted ? (size_t)c->stat_entries : 0)) a.v2 = false;
+        if (mine && a.v2 && !tile_lists_plan(lane(c).tl, (size_t)c->tiles_x * c->tiles_y, a.instances, c->slabs, a.keybits, a.key_span)) a.v2 = false;
         if (mine) {
             // on the ordered path too: the projection writes the keys, the sort follows it, the binning reads the sorted index
             if (!a.v2) { a.ks = lane(c).kg_ks; a.keybits = lane(c).kg_bits; a.key_span = lane(c).kg_span; }
@@ -1089,7 +1061,7 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     rc = run_draw(c, a, true);
     a.fuse = false;                    // a re-run of this draw finds the keys written and the sort queued
     if (rc) { L.proj_n = before; return rc; }
-    if (L.proj_n) { L.pending = true; L.pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; if (a.v2) c->stat_v2_draws++; if (a.v2 && a.sorted) c->stat_sorted_draws++; }   // proj_n != 0 <=> raster work was enqueued
+    if (L.proj_n) { L.pending = true; L.pending_args = a; c->fbs[c->cur_fb].is_clear = false; L.drawn = true; if (a.v2) c->stat_v2_draws++; }   // proj_n != 0 <=> raster work was enqueued
     else L.proj_n = before;
     if (c->profiling) { if (c->prof_frame < gs4d_ctx::PROF_FRAMES && c->prof_tick % (uint64_t)c->prof_every == 0) c->prof_frame++; c->prof_tick++; }
     return GS4D_OK;
@@ -1348,7 +1320,7 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     if (!c || !stats) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = ((uint64_t)c->tiles_x * c->tiles_y) | (c->stat_sorted_draws << 32);
+    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
     stats[4] = c->stat_depth_passes; stats[5] = (c->stat_tile_passes & 0xFFFFFFFFull) | (c->stat_renamed << 32); stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }

@@ -144,13 +144,6 @@ hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uin
 // skey == nullptr: the blend keys the projection left in t.skey; else an array of key bit patterns from which skey_bias is still to be subtracted (the caller's key buffer of a fused draw)
 hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint);
-// long lists (tilelist.hip): the scatter with its segment staged in LDS; the bucket-wide sort that leaves every tile's list ordered (flag 4 in total[1]: a bucket
-// larger than the sort holds); the compositor that walks ordered lists (composite2.hip).  The lists must have been planned with ONE slab.
-hipError_t launch_bucket_scatter_staged(hipStream_t st, TileLists& t, const uint2* rects, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world,
-                                        size_t expect_per_segment);
-hipError_t launch_bucket_sort(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, int key_bits, int rec_bits, size_t expect_per_bucket);
-hipError_t launch_composite_walk(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
-                                 int premult_c, int fb_is_clear, const float clear[4], float4* fb);
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs);
 

@@ -225,238 +225,12 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
     // (the entry count, the longest list and the flags reach the host through the compositing kernel that follows: no hand-off here)
 }
 
-// ---- long tile lists: staged scatter + bucket sort ------------------------------------------------------------------------------------
-// The wave that composites a tile can order a list of a few hundred entries in its own LDS (composite2.hip).  10^7 splats at 1080p put
-// ~1500 entries on the average non-empty tile and 4400 on the busiest: there the lists are ordered HERE, a bucket at a time — a bucket is
-// the unit that is already in one workgroup's hands — and the compositor just walks them.
-
-// exclusive scan of nb <= 1024 values held two per thread by a 512-thread workgroup; returns the total
-__device__ __forceinline__ uint32_t scan2_512(uint32_t v0, uint32_t v1, uint32_t& e0, uint32_t& e1, uint32_t* ws /* __shared__[8] */) {
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t sum = v0 + v1;
-    uint32_t inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += t; }
-    __syncthreads();                                           // ws may still be read from an earlier call
-    if (lane == 63u) ws[w] = inc;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < SEG_THREADS / 64; ++k) { const uint32_t t = ws[k]; if ((unsigned)k < w) base += t; tot += t; }
-    e0 = base + inc - sum; e1 = e0 + v0;
-    return tot;
-}
-
-// k_bucket_scatter with the segment's entries STAGED in LDS in bucket order and written out run by run.  Written one by one, the entries
-// of a segment land 8 bytes at a time all over the bucket array — 1.4e7 partial-line writes at 10^7 splats, each costing the memory system
-// a whole line: the kernel ran at the price of 880 MB for 110 MB of data.  Here run (segment, bucket) leaves the workgroup as one
-// contiguous piece.  A segment whose entries do not fit the staging area (CAP) is written directly, as before.
-template <uint32_t CAP>
-__global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter_staged(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t skey_bias, uint32_t n, uint32_t seg, uint32_t nb,
-                                                                       const uint32_t* __restrict__ hist /* [nb][rows] counts */, uint32_t rows,
-                                                                       const uint32_t* __restrict__ offs, const uint32_t* __restrict__ bbase, const uint32_t* __restrict__ total, uint2* __restrict__ tmp,
-                                                                       uint32_t tiles_x, uint32_t shard_rank, uint32_t shard_world) {
-    __shared__ uint2 stage[CAP];
-    __shared__ uint32_t lstart[1025];
-    __shared__ uint32_t cur[1024];
-    __shared__ uint32_t ws[SEG_THREADS / 64];
-    if (total[1] & 1u) return;                             // aborted draw: slots would lie beyond the capacity
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = blockIdx.x;
-    // this segment's count per bucket (the projection left it in the count matrix) -> where its run starts in the staging area
-    const uint32_t b0 = 2u * tid, b1 = b0 + 1u;
-    const uint32_t c0 = b0 < nb ? hist[(size_t)b0 * rows + w] : 0u, c1 = b1 < nb ? hist[(size_t)b1 * rows + w] : 0u;
-    uint32_t e0, e1;
-    const uint32_t T = scan2_512(c0, c1, e0, e1, ws);
-    const bool staged = T <= CAP;                          // uniform
-    if (b0 < nb) { lstart[b0] = e0; cur[b0] = staged ? e0 : bbase[b0] + offs[(size_t)w * nb + b0]; }
-    if (b1 < nb) { lstart[b1] = e1; cur[b1] = staged ? e1 : bbase[b1] + offs[(size_t)w * nb + b1]; }
-    if (tid == 0) lstart[nb] = T;
-    __syncthreads();
-    const uint32_t nbm = nb - 1u, nbs = (uint32_t)__ffs((int)nb) - 1u;
-    const uint32_t i0 = w * seg, i1 = min(n, i0 + seg);
-    constexpr int SC_ITEMS = 4;                            // records per thread and round: all their loads are in flight before the first LDS atomic
-    auto put = [&](uint32_t pos, const uint2& e) { if (staged) { if (pos < CAP) stage[pos] = e; } else tmp[pos] = e; };      // (pos < CAP always holds; the test keeps a corrupt count matrix inside LDS)
-    for (uint32_t ib = i0; ib < i1; ib += SEG_THREADS * SC_ITEMS) {      // uniform trip count: every lane stays to the end
-        uint2 rc[SC_ITEMS]; uint32_t kk[SC_ITEMS];
-#pragma unroll
-        for (int q = 0; q < SC_ITEMS; ++q) {
-            const uint32_t i = ib + (uint32_t)q * SEG_THREADS + tid;
-            rc[q] = i < i1 ? rects[i] : make_uint2(1u, 0u);
-            kk[q] = i < i1 ? skey[i] - skey_bias : 0u;
-        }
-#pragma unroll
-        for (int q = 0; q < SC_ITEMS; ++q) {
-            const uint32_t i = ib + (uint32_t)q * SEG_THREADS + tid;
-            const TRect r = tile_rect(rc[q].x, rc[q].y, shard_rank, shard_world);
-            const uint32_t key = kk[q];
-            const bool big = r.count > 16u;
-            if (!big) for_each_tile(r, tiles_x, [&](uint32_t t) {
-                const uint32_t pos = atomicAdd(&cur[t & nbm], 1u);
-                put(pos, make_uint2(key, ((t >> nbs) << 24) | i));
-            });
-            uint64_t m = __ballot(big);
-            while (m) {                                    // large footprints: the whole wave writes one record's entries
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1ull;
-                TRect rr;
-                rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
-                rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
-                const uint32_t key2 = __shfl(key, src, 64), rec2 = __shfl(i, src, 64);
-                for (uint32_t j = lane; j < rr.count; j += 64u) {
-                    const uint32_t t = tile_of(rr, j, tiles_x);
-                    const uint32_t pos = atomicAdd(&cur[t & nbm], 1u);
-                    put(pos, make_uint2(key2, ((t >> nbs) << 24) | rec2));
-                }
-            }
-        }
-    }
-    if (!staged) return;                                   // uniform
-    __syncthreads();
-    // run (w, b): stage[lstart[b] .. lstart[b + 1]) -> tmp[bbase[b] + offs[w][b] ..], consecutive lanes on consecutive entries; two runs per wave round
-    const uint32_t half = lane >> 5, hl = lane & 31u;
-    for (uint32_t b = (tid >> 6) * 2u + half; b < nb; b += (SEG_THREADS / 64) * 2u) {
-        const uint32_t s = lstart[b], c = lstart[b + 1u] - s;
-        if (c == 0u) continue;
-        const uint32_t g = bbase[b] + offs[(size_t)w * nb + b];
-        for (uint32_t i = hl; i < c; i += 32u) tmp[g + i] = stage[s + i];
-    }
-}
-
-// Bucket b -> its tiles' lists, each ORDERED by (key, record): a stable LSD radix sort of the whole bucket in LDS — 8-bit digits of the key,
-// then the tile (tile / nb: the top byte of an entry's record word) — by 1024 threads holding ITEMS entries each.  Ranking by returning
-// LDS atomics on one counter row per wave (stable because the LDS unit serves the lanes of an instruction that meet on one counter in lane
-// order — the property sort.hip's passes rely on, verified on the device at context creation — and element order is wave-major, item-major,
-// lane order).  A digit every entry agrees on is skipped.  Entries that tie on (tile, key) are rare (24-bit depth keys): detected after the
-// sort by a neighbour test, and only then is the bucket sorted on the record index first and on key and tile again.  The sorted bucket IS
-// the concatenation of its tiles' lists: written back in place of the bucket, fully coalesced; the tile table gets (first entry, count).
-// A bucket of more than 1024 * ITEMS entries raises flag 4: the host re-runs the draw on the instance-ordered path.
-constexpr int BS_THREADS = 1024, BS_WAVES = BS_THREADS / 64;
-template <int ITEMS>
-struct BucketSort {
-    uint32_t k[ITEMS], r[ITEMS];
-    // digit source: 0..3 = byte of the key, 4 = tile byte of the record word, 5..7 = byte 0..2 of the record index
-    __device__ __forceinline__ uint32_t digit(int j, int what) const { return what < 4 ? (k[j] >> (8 * what)) & 255u : what == 4 ? r[j] >> 24 : (r[j] >> (8 * (what - 5))) & 255u; }
-    __device__ __forceinline__ void pass(int what, uint32_t E, uint32_t* ek, uint32_t* er, uint32_t (*wcnt)[256], uint32_t* loff, uint32_t* s_tmp, uint32_t* s_skip) {
-        const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-        const uint32_t base = w * (64u * ITEMS);
-        for (uint32_t q = tid; q < BS_WAVES * 256u; q += BS_THREADS) (&wcnt[0][0])[q] = 0u;
-        if (tid == 0) *s_skip = 0u;
-        __syncthreads();
-        uint32_t rank[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { rank[j] = 0u; if (base + j * 64u + lane < E) rank[j] = atomicAdd(&wcnt[w][digit(j, what)], 1u); }
-        __syncthreads();
-        uint32_t cnt = 0;
-        if (tid < 256u) {
-#pragma unroll
-            for (int q = 0; q < BS_WAVES; ++q) { const uint32_t t = wcnt[q][tid]; wcnt[q][tid] = cnt; cnt += t; }
-            if (cnt == E) *s_skip = 1u;                    // one digit holds every entry: a stable identity
-        }
-        // exclusive scan of the 256 digit totals (threads 0..255 = waves 0..3 carry a value; everybody takes part in the barriers)
-        uint32_t inc = tid < 256u ? cnt : 0u;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += t; }
-        if (lane == 63u && w < 4u) s_tmp[w] = inc;
-        __syncthreads();
-        if (*s_skip) { __syncthreads(); return; }          // uniform
-        if (tid < 256u) { uint32_t b2 = 0; for (uint32_t q = 0; q < w; ++q) b2 += s_tmp[q]; loff[tid] = b2 + inc - cnt; }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) if (base + j * 64u + lane < E) { const uint32_t d = digit(j, what); const uint32_t l = loff[d] + wcnt[w][d] + rank[j]; ek[l] = k[j]; er[l] = r[j]; }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const uint32_t i = base + j * 64u + lane; if (i < E) { k[j] = ek[i]; r[j] = er[i]; } }
-        __syncthreads();
-    }
-};
-
-template <int ITEMS>
-__global__ __launch_bounds__(BS_THREADS) void k_bucket_sort(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles, int key_passes, int rec_passes,
-                                                            uint32_t* __restrict__ tstart, uint32_t* __restrict__ tcnt, uint2* __restrict__ entries, uint32_t* __restrict__ total) {
-    constexpr uint32_t CAP = BS_THREADS * ITEMS;
-    __shared__ uint32_t ek[CAP];
-    __shared__ uint32_t er[CAP];
-    __shared__ uint32_t wcnt[BS_WAVES][256];
-    __shared__ uint32_t loff[256];
-    __shared__ uint32_t s_tmp[4];
-    __shared__ uint32_t s_skip, s_tie;
-    if (total[1] & 1u) return;                             // capacity overflow (k_bucket_scan): nothing was scattered
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
-    const uint32_t lo = bbase[b], hi = bbase[b + 1];
-    const uint32_t E = hi - lo;
-    const uint32_t tpb = (ntiles + nb - 1u) / nb;          // tiles of a bucket: h * nb + b, h < tpb <= 256
-    if (E > CAP) {                                         // uniform
-        if (tid == 0) atomicOr(&total[1], 4u);
-        return;
-    }
-    BucketSort<ITEMS> bs;
-    const uint32_t base = w * (64u * ITEMS);
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t i = base + j * 64u + lane;
-        bs.k[j] = 0xFFFFFFFFu; bs.r[j] = 0xFFFFFFFFu;
-        if (i < E) { const uint2 e = tmp[lo + i]; bs.k[j] = e.x; bs.r[j] = e.y; }
-    }
-    if (tid == 0) s_tie = 0u;
-    if (E > 1u) {
-        for (int p = 0; p < key_passes; ++p) bs.pass(p, E, ek, er, wcnt, loff, s_tmp, &s_skip);
-        bs.pass(4, E, ek, er, wcnt, loff, s_tmp, &s_skip);
-    }
-    // the sorted sequence to LDS (the last pass may have been an identity that wrote nothing): neighbour test, tile table, write-back
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { const uint32_t i = base + j * 64u + lane; if (i < E) { ek[i] = bs.k[j]; er[i] = bs.r[j]; } }
-    __syncthreads();
-    bool tie = false;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { const uint32_t i = base + j * 64u + lane; if (i + 1u < E) tie |= ek[i] == ek[i + 1u] && (er[i] >> 24) == (er[i + 1u] >> 24); }
-    if (__ballot(tie) != 0ull && lane == 0u) s_tie = 1u;
-    __syncthreads();
-    if (s_tie) {                                           // uniform: equal keys on one tile — instance order among them is ascending record index
-        for (int p = 0; p < rec_passes; ++p) bs.pass(5 + p, E, ek, er, wcnt, loff, s_tmp, &s_skip);
-        for (int p = 0; p < key_passes; ++p) bs.pass(p, E, ek, er, wcnt, loff, s_tmp, &s_skip);
-        bs.pass(4, E, ek, er, wcnt, loff, s_tmp, &s_skip);
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) { const uint32_t i = base + j * 64u + lane; if (i < E) { ek[i] = bs.k[j]; er[i] = bs.r[j]; } }
-        __syncthreads();
-    }
-    // tile table: entry i opens tile h's list if its predecessor belongs to another tile; the list ends where the next one opens
-    for (uint32_t q = tid; q < 256u; q += BS_THREADS) { loff[q] = 0xFFFFFFFFu; }      // first entry of tile-high q (none)
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t i = base + j * 64u + lane;
-        if (i < E) { const uint32_t h = er[i] >> 24; if (i == 0u || (er[i - 1u] >> 24) != h) loff[h] = i; }
-    }
-    __syncthreads();
-    uint32_t mx = 0;
-    if (tid < 256u && tid < tpb) {
-        const uint32_t tile = tid * nb + b;
-        if (tile < ntiles) {
-            const uint32_t s0 = loff[tid];
-            uint32_t c = 0;
-            if (s0 != 0xFFFFFFFFu) {                       // ends at the next tile-high that has entries, or at the bucket's end
-                uint32_t e1 = E;
-                for (uint32_t q = tid + 1u; q < tpb; ++q) { const uint32_t sq = loff[q]; if (sq != 0xFFFFFFFFu) { e1 = sq; break; } }
-                c = e1 - s0;
-            }
-            tstart[tile] = lo + (s0 == 0xFFFFFFFFu ? 0u : s0);
-            tcnt[tile] = c;
-            mx = c;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
-    if (lane == 0u && mx) atomicMax(&total[4], mx);
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) { const uint32_t i = base + j * 64u + lane; if (i < E) entries[lo + i] = make_uint2(bs.k[j], bs.r[j] & 0x00FFFFFFu); }
-}
-
 bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span, size_t expect_entries) {
     if (nrecords == 0 || nrecords > V2_MAX_RECORDS) return false;
     // buckets: enough that tile / nb < 256, and about 8192 entries each (k_bucket_tiles reads a bucket of that size once) at ~1.4 entries per
-    // record — or, when the scene's entry count is known from an earlier draw (long lists: the bucket sort holds 8192 / 16384 entries), ~6000 each
+    // record, or at what an earlier draw of the scene counted
     uint32_t nb = 64;
-    const size_t est = expect_entries ? expect_entries + expect_entries / 3 : nrecords + nrecords / 2;
+    const size_t est = expect_entries ? expect_entries + expect_entries / 8 : nrecords + nrecords / 2;
     while (((size_t)nb * 256 < ntiles || (size_t)nb * 8192 < est) && nb < 1024) nb *= 2;
     if (const char* ev = getenv("GS4D_NB")) {            // tuning knob: number of buckets (a power of two, 64..1024), subject to the entry format
         const uint32_t v = (uint32_t)atoi(ev);
@@ -524,27 +298,6 @@ hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uin
 
 hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
     k_bucket_scatter<<<dim3(t.rows), dim3(SEG_THREADS), 0, st>>>(rects, skey ? skey : t.skey, skey ? skey_bias : 0u, (uint32_t)nrecords, t.seg, t.nb, t.hist + t.hist_cap, t.bbase, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
-    return hipGetLastError();
-}
-
-// expected entries per segment decides the staging area (LDS per workgroup: 8 bytes per entry); 0 or more than the largest: the direct kernel
-hipError_t launch_bucket_scatter_staged(hipStream_t st, TileLists& t, const uint2* rects, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world,
-                                        size_t expect_per_segment) {
-    const uint32_t* sk = skey ? skey : t.skey; const uint32_t bias = skey ? skey_bias : 0u;
-#define GS4D_STAGED(C) k_bucket_scatter_staged<C><<<dim3(t.rows), dim3(SEG_THREADS), 0, st>>>(rects, sk, bias, (uint32_t)nrecords, t.seg, t.nb, t.hist, t.rows, t.hist + t.hist_cap, t.bbase, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world)
-    if (expect_per_segment == 0 || expect_per_segment > 16384) return launch_bucket_scatter(st, t, rects, skey, skey_bias, nrecords, total, tmp, tiles_x, shard_rank, shard_world);
-    if (expect_per_segment <= 4096) GS4D_STAGED(4096);
-    else if (expect_per_segment <= 8192) GS4D_STAGED(8192);
-    else GS4D_STAGED(16384);
-#undef GS4D_STAGED
-    return hipGetLastError();
-}
-
-// key_bits / rec_bits: live bits of the blend key and of the record index (8-bit passes)
-hipError_t launch_bucket_sort(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, int key_bits, int rec_bits, size_t expect_per_bucket) {
-    const int kp = std::max(1, (key_bits + 7) / 8), rp = std::max(1, std::min(3, (rec_bits + 7) / 8));
-    if (expect_per_bucket <= 8192) k_bucket_sort<8><<<dim3(t.nb), dim3(BS_THREADS), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, kp, rp, t.tstart, t.tcnt, entries, total);
-    else k_bucket_sort<16><<<dim3(t.nb), dim3(BS_THREADS), 0, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, kp, rp, t.tstart, t.tcnt, entries, total);
     return hipGetLastError();
 }
 

@@ -94,19 +94,18 @@ def test_equal_depth_keys_blend_in_index_order(gs4d, oracle, monkeypatch):
     assert linf(other, eimg) > 1e-2
 
 
-def test_long_lists_grow_the_compositor_then_the_bucket_sort_then_fall_back(gs4d, oracle, monkeypatch):
-    """Hundreds, then thousands, of splats on the same pixels.  The list-building kernels report the longest list.  Up to 512 entries
-    the compositing wave orders a tile's list itself (re-run with a larger LDS capacity when needed); longer lists are ordered by the
-    bucket-wide sort and walked — also when every key is the same (the bucket sort breaks ties on the record index); a bucket beyond what
-    that sort holds (16 384 entries) sends the draw to the instance-ordered path.  Every time the same picture."""
+def test_long_lists_grow_the_compositor_then_fall_back(gs4d, oracle, monkeypatch):
+    """Hundreds, then thousands, of splats on the same pixels.  The list-building kernels report the longest list; the draw is re-run with
+    a larger LDS list capacity in the compositing wave (up to 1024 entries), and beyond that on the instance-ordered path — where the
+    context then stays.  Every time the same picture."""
     W, H = 256, 256
     cam = ((0.0, 0.0, 60.0), (0.0, 0.0, -1.0))
     view, proj = cam_mats(gs4d, cam, W, H)
     ctx = _ctx(gs4d, W, H, monkeypatch)
     seen = []
-    for n, spread in ((400, 0.1), (400, 0.1), (2500, 0.1), (3000, 0.0), (20000, 0.1), (120, 0.1)):
+    for n, spread in ((700, 0.1), (700, 0.1), (2500, 0.1), (3000, 0.0), (120, 0.1)):
         pos, q, sc, rgba = scenes.cube_params(n, seed=50 + n)
-        rgba[:, 3] *= 0.05 if n < 10000 else 0.004
+        rgba[:, 3] *= 0.05
         pos[:, 0:2] = 0.0                                                     # all on the view axis: one spot of the image; spread 0: one depth, equal keys
         rec = gs4d.build_records_3d(pos * spread, q, sc * 1.5, rgba)
         img, perm, _, st = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
@@ -115,15 +114,13 @@ def test_long_lists_grow_the_compositor_then_the_bucket_sort_then_fall_back(gs4d
         assert linf(img, eimg) <= TOL
         assert np.abs(eimg - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.05
         seen.append(st)
-    # frame 1: unordered, re-run with a longer list capacity in the compositing wave; frame 2: the same, no re-run
-    assert seen[0]["unordered_draws"] == 1 and seen[0]["reruns"] == 1 and 256 < seen[0]["longest_list"] <= 400 and seen[0]["tile_sort_passes"] == 0 and seen[0]["bucket_sorted_draws"] == 0
-    assert seen[1]["unordered_draws"] == 2 and seen[1]["reruns"] == 1 and seen[1]["bucket_sorted_draws"] == 0
-    # frame 3: 2500 entries on a tile: one re-run, on the bucket sort; frame 4: 3000 entries with ONE key: the bucket sort again, at once (ties go by record index)
-    assert seen[2]["reruns"] == 2 and seen[2]["bucket_sorted_draws"] == 1 and seen[2]["tile_sort_passes"] == 0 and 2000 < seen[2]["longest_list"] <= 2500
-    assert seen[3]["reruns"] == 2 and seen[3]["bucket_sorted_draws"] == 2 and seen[3]["tile_sort_passes"] == 0
-    # frame 5: 20000 entries on one tile = in one bucket: 8 per thread, then 16 per thread, then the instance-ordered path; frame 6 stays there
-    assert seen[4]["reruns"] == 4 and seen[4]["tile_sort_passes"] >= 2
-    assert seen[5]["unordered_draws"] == seen[4]["unordered_draws"] and seen[5]["reruns"] == seen[4]["reruns"] and seen[5]["tile_sort_passes"] >= 2
+    # frame 1: unordered, re-run with a longer list capacity; frame 2: unordered, no re-run
+    assert seen[0]["unordered_draws"] == 1 and seen[0]["reruns"] == 1 and 256 < seen[0]["longest_list"] <= 700 and seen[0]["tile_sort_passes"] == 0
+    assert seen[1]["unordered_draws"] == 2 and seen[1]["reruns"] == 1 and seen[1]["tile_sort_passes"] == 0
+    # frame 3: 2500 entries on a tile: more than the compositing wave holds -> one re-run, on the instance-ordered path; frames 4 and 5 stay there
+    assert seen[2]["reruns"] == 2 and seen[2]["tile_sort_passes"] >= 2
+    assert seen[3]["unordered_draws"] == seen[2]["unordered_draws"] and seen[3]["reruns"] == 2 and seen[3]["tile_sort_passes"] >= 2
+    assert seen[4]["unordered_draws"] == seen[2]["unordered_draws"] and seen[4]["reruns"] == 2 and seen[4]["tile_sort_passes"] >= 2
     ctx.close()
 
 
@@ -143,7 +140,7 @@ def test_depth_slabs(gs4d, oracle, monkeypatch, slabs):
     img, perm, _, st = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
     ctx.close()
     assert np.array_equal(perm, eperm) and linf(img, eimg) <= TOL
-    assert st["unordered_draws"] >= 1 and st["tile_sort_passes"] == 0 and st["bucket_sorted_draws"] == 0
+    assert st["unordered_draws"] >= 1 and st["tile_sort_passes"] == 0
     ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_DRAW_PATH="ordered")
     img_o, _, _, _ = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
     ctx.close()
@@ -162,10 +159,10 @@ def test_depth_slabs(gs4d, oracle, monkeypatch, slabs):
     assert np.array_equal(perm2, eperm2) and linf(img2, eimg2) <= TOL and st2["tile_sort_passes"] >= 2
 
 
-def test_bucket_sorted_lists_match_the_other_paths(gs4d, oracle, monkeypatch):
-    """A dense cloud (lists of a few thousand entries on the busiest tiles): the draw ends on the bucket-sorted path, with the same frame as
-    the instance-ordered path bit for bit (same records, same order, same chunking) — for the reference's key, for keys that tie, and for
-    instance-index order (4D-direct)."""
+def test_long_lists_in_a_dense_cloud(gs4d, oracle, monkeypatch):
+    """A dense cloud (lists of a few thousand entries on the busiest tiles, keys that tie in pairs): the draw is issued on the unordered path,
+    aborts on the device and is re-run on the instance-ordered path from a REGENERATED order (it never read the caller's index): same frame as
+    with that path forced, bit for bit; and instance-index order (4D-direct) on the same context."""
     n, W, H = 300000, 640, 360
     pos, q, sc, rgba = scenes.cube_params(n, seed=63)
     rgba[:, 3] *= 0.2
@@ -181,15 +178,13 @@ def test_bucket_sorted_lists_match_the_other_paths(gs4d, oracle, monkeypatch):
         assert np.array_equal(perm, eperm)
         assert linf(img, eimg) <= TOL
         if path == "auto":
-            assert st["bucket_sorted_draws"] >= 1 and st["tile_sort_passes"] == 0 and st["longest_list"] > 1024
-            # instance-index order on the same path
+            assert st["unordered_draws"] == 1 and st["reruns"] >= 1 and st["tile_sort_passes"] >= 2 and st["longest_list"] > 1024
             db = ctx.buffer(rec)
             ctx.clear()
             ctx.set_mode(gs4d.MODE_4D_DIRECT)
             ctx.bind(1, db)
             ctx.draw_instanced(n)
             direct = ctx.read_pixels()
-            assert ctx.stats()["bucket_sorted_draws"] > st["bucket_sorted_draws"]
             eproj = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H)
             edirect = oracle.composite(eproj, None, oracle.MODE_4D, W, H, oracle.clear_image(W, H), nthreads=16)
             assert linf(direct, edirect) <= TOL
