@@ -8,8 +8,9 @@
 //
 // Counts stay on the device: the total number of entries is written to total[0] (and an overflow flag to total[1] when it
 // exceeds the preallocated capacity); later kernels read it there, so a frame needs no host synchronisation.
-// Counting, scanning and emitting are ONE launch (chained scan over workgroup totals); the per-record pixel rectangles are read
-// from a compact 8-byte array (L2/Infinity-Cache resident) instead of the 64-byte projected records.
+// Counting, scanning and emitting are ONE launch (chained scan over workgroup totals); the per-record tile rectangles are read
+// from a compact 4-byte array (pack_trect, gs4d_internal.h) instead of the 64-byte projected records — gathered through the sort index,
+// or, when the depth sort carried them along as a second payload (a draw that generated its own keys), streamed in instance order.
 #include "gs4d_internal.h"
 #include <cstdlib>
 
@@ -71,7 +72,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return v;
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restrict__ rects, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
+__global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ trects, int trects_in_order, const float4* __restrict__ proj, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
                                                           unsigned long long* status, unsigned long long* gstatus, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
                                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
                                                           uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base, int dbg_arg,
@@ -102,18 +103,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint2* __restric
             rec[j] = order ? order[k] : k;
             if (order_copy) order_copy[k] = rec[j];      // the draw keeps its own copy: the caller may refill the buffer for the next frame
             if (rec[j] < nrecords) {              // an index past the bound SSBO: GL would read undefined data; we draw nothing
-                const uint2 rr = (dbg & 1) ? make_uint2((k % 1900u) | ((k % 1070u) << 16), ((k % 1900u) + 2u) | (((k % 1070u) + 2u) << 16)) : rects[rec[j]];
-                const uint32_t x0 = rr.x & 0xFFFFu, y0 = rr.x >> 16, x1 = rr.y & 0xFFFFu, y1 = rr.y >> 16;
-                if (x0 <= x1 && y0 <= y1) {
-                    r[j].tx0 = x0 / TILE; r[j].ty0 = y0 / TILE; r[j].tx1 = x1 / TILE; r[j].ty1 = y1 / TILE;
-                    uint32_t rows = r[j].ty1 - r[j].ty0 + 1u;
-                    if (shard_world > 1u) {            // only the tile rows this context owns (single-frame sharding over several GPUs)
-                        const uint32_t first = r[j].ty0 + (shard_rank + shard_world - r[j].ty0 % shard_world) % shard_world;
-                        rows = first > r[j].ty1 ? 0u : (r[j].ty1 - first) / shard_world + 1u;
-                        r[j].ty0 = first; r[j].tstep = shard_world;
-                    }
-                    r[j].count = (r[j].tx1 - r[j].tx0 + 1u) * rows;
-                }
+                const uint32_t word = (dbg & 1) ? ((k % 230u) | ((k % 130u) << 10)) : trects[trects_in_order ? k : rec[j]];
+                const TRect t = unpack_trect(word, proj, rec[j], shard_rank, shard_world);      // only the tile rows this context owns (single-frame sharding over several GPUs)
+                if (t.count) { r[j].tx0 = t.tx0; r[j].ty0 = t.ty0; r[j].tx1 = t.tx0 + t.wx - 1u; r[j].ty1 = t.ty0 + (t.rows - 1u) * t.tstep; r[j].tstep = t.tstep; r[j].count = t.count; }
             }
         }
     }
@@ -246,7 +238,7 @@ void bin_scratch_free(BinScratch& b) {
     b = BinScratch();
 }
 
-hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
+hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint32_t* trects, bool trects_in_order, const float4* proj, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
                           uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host, int shard_rank, int shard_world) {
     (void)tiles_y;
 #ifdef GS4D_TUNING
@@ -260,7 +252,7 @@ hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, con
         b.epoch = 1;
     }
     const uint32_t nb = (uint32_t)((ninst + BIN_THREADS * BIN_ITEMS - 1) / (BIN_THREADS * BIN_ITEMS));
-    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(rects, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.status + b.block_cap, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch, b.total + 8, b.ticket_base, dbg, (uint32_t)shard_rank, (uint32_t)shard_world);
+    k_bin_emit<<<dim3(nb), dim3(BIN_THREADS), 0, st>>>(trects, trects_in_order ? 1 : 0, proj, order, order_copy, (uint32_t)ninst, (uint32_t)nrecords, b.status, b.status + b.block_cap, b.total, (uint32_t)pair_cap, (uint32_t)tiles_x, pair_keys, pair_vals, err, ghist, passes, total_host, b.epoch, b.total + 8, b.ticket_base, dbg, (uint32_t)shard_rank, (uint32_t)shard_world);
     b.ticket_base += nb;
     return hipGetLastError();
 }

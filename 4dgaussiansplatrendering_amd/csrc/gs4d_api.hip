@@ -92,7 +92,8 @@ struct Lane {
     hipEvent_t ev_emit = nullptr;      // the lane's latest binning kernel has finished (it read and copied the sort index; its entry count is final)
     hipEvent_t ev_tail = nullptr;      // recorded when the lane is left: everything queued on it so far
     bool drawn = false;                // the lane's current frame has a draw in it: the next frame-starting call moves on
-    float4* proj = nullptr; uint2* rects = nullptr; size_t proj_cap = 0, proj_n = 0;   // projected records (64 B) and their pixel rectangles
+    float4* proj = nullptr; uint32_t* trects = nullptr; size_t proj_cap = 0, proj_n = 0;   // projected records (64 B) and their packed tile rectangles (4 B)
+    bool trects_in_order = false;      // the last draw's tile rectangles are in INSTANCE order (they went through its depth sort), not in record order
     uint32_t* pair_keys = nullptr; uint32_t* pair_vals = nullptr; size_t pair_cap = 0;   // tile-list entries: one allocation of 8 * pair_cap bytes — (tile ids | records) on the ordered path, (key, record) pairs on the unordered one
     TileLists tl;                      // unordered path: per-tile counts / starts / cursors, per-record blend keys
     uint32_t* order_copy = nullptr; size_t order_cap = 0;   // private copy of the last draw's sort index (for a re-run after overflow)
@@ -335,7 +336,7 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, cons
         hipError_t he = hipSuccess;
         uint32_t* ph = sort_hist_slot(L.s, L.pair_sort, L.pair_cap, &he);      // the emit kernel also counts the tile-id digits
         if (!ph) return hipfail(c, he, "sort_hist_slot");
-        HIPCHK(c, launch_binning(L.s, L.bin, L.rects, order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, L.pair_keys, L.pair_vals, L.pair_cap, L.host_total_dev + 4,
+        HIPCHK(c, launch_binning(L.s, L.bin, L.trects, L.trects_in_order, L.proj, order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, L.pair_keys, L.pair_vals, L.pair_cap, L.host_total_dev + 4,
                                  ph, tile_passes, L.host_total_dev, a.shard_rank, a.shard_world));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));     // the last binning workgroup wrote the total straight into pinned host memory
@@ -363,7 +364,7 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
         HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
         const uint32_t* fused_keys = nullptr;
         if (a.fuse) { Buffer* K = getbuf(c, a.fuse_keys); if (K) fused_keys = (const uint32_t*)K->d; }      // the projection wrote the keys there and nowhere else
-        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.rects, fused_keys, a.ks.bias, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world));
+        HIPCHK(c, launch_bucket_scatter(L.s, L.tl, L.trects, L.proj, fused_keys, a.ks.bias, nrecords, L.bin.total, tmp, c->tiles_x, a.shard_rank, a.shard_world));
         HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
     }
     c->stat_tile_passes = 0;
@@ -422,9 +423,9 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
         if (L.proj_cap < npre) {
             HIPCHK(c, hipStreamSynchronize(L.s));
             if (L.proj) (void)hipFree(L.proj);
-            if (L.rects) (void)hipFree(L.rects);
-            L.proj = nullptr; L.rects = nullptr; L.proj_cap = 0;
-            HIPCHK(c, hipMalloc(&L.proj, npre * 64)); HIPCHK(c, hipMalloc(&L.rects, npre * 8));
+            if (L.trects) (void)hipFree(L.trects);
+            L.proj = nullptr; L.trects = nullptr; L.proj_cap = 0;
+            HIPCHK(c, hipMalloc(&L.proj, npre * 64)); HIPCHK(c, hipMalloc(&L.trects, npre * 4));
             L.proj_cap = npre;
         }
         if (!a.quads && (a.mode == GS4D_MODE_4D_SORTED || a.mode == GS4D_MODE_4D_DIRECT)) { int rc = ensure_soa(c, *data); if (rc) return rc; }
@@ -432,7 +433,8 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
         if (ob && !v2) { int rc = lane_access(c, *ob, false); if (rc) return rc; ob->rd_mask |= 1u << a.lane; }
         {
             StageTimer t(c, GS4D_T_PREPROCESS);
-            const PreOut po = { L.proj, L.rects };
+            const PreOut po = { L.proj, L.trects };
+            L.trects_in_order = false;
             TileCount tc;
             if (v2) { tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.rows = L.tl.rows; tc.tiles_x = c->tiles_x; tc.shard_rank = a.shard_rank; tc.shard_world = a.shard_world; tc.ks = a.ks; }
             if (a.fuse) {
@@ -675,7 +677,7 @@ void gs4d_destroy(gs4d_ctx* c) {
         if (L.regen_keys) (void)hipFree(L.regen_keys);
         for (auto& sp : L.spare) { if (sp.d) (void)hipFree(sp.d); for (hipEvent_t e : sp.ev) if (e) (void)hipEventDestroy(e); }
         if (L.proj) (void)hipFree(L.proj);
-        if (L.rects) (void)hipFree(L.rects);
+        if (L.trects) (void)hipFree(L.trects);
         if (L.pair_keys) (void)hipFree(L.pair_keys);
         tile_lists_free(L.tl);
         sort_scratch_free(L.depth_sort); sort_scratch_free(L.pair_sort); bin_scratch_free(L.bin);

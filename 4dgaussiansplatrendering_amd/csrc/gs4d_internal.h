@@ -142,7 +142,7 @@ void tile_lists_free(TileLists& t);
 // [6] workgroups of k_bucket_tiles that have finished, [7] of k_bucket_scan (back to 0 when the kernel ends); total_host (pinned, mapped) receives [0..3] and the longest list at [5]
 hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap);
 // skey == nullptr: the blend keys the projection left in t.skey; else an array of key bit patterns from which skey_bias is still to be subtracted (the caller's key buffer of a fused draw)
-hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint32_t* trects, const float4* proj, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint);
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs);
@@ -150,13 +150,9 @@ hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* 
 #ifdef __HIPCC__
 // tiles touched by a pixel rectangle (x0|y0<<16, x1|y1<<16; x0 > x1: none), restricted to the tile rows ty % world == rank
 struct TRect { uint32_t tx0, ty0, wx, rows, tstep, count; };
-__device__ __forceinline__ TRect tile_rect(uint32_t rect0, uint32_t rect1, uint32_t shard_rank, uint32_t shard_world) {
-    TRect r{ 0u, 0u, 0u, 0u, 1u, 0u };
-    const uint32_t x0 = rect0 & 0xFFFFu, y0 = rect0 >> 16, x1 = rect1 & 0xFFFFu, y1 = rect1 >> 16;
-    if (x0 > x1 || y0 > y1) return r;
-    r.tx0 = x0 / TILE; r.ty0 = y0 / TILE; r.wx = x1 / TILE - r.tx0 + 1u;
-    const uint32_t ty1 = y1 / TILE;
-    r.rows = ty1 - r.ty0 + 1u;
+// tiles tx0 .. tx0 + wx - 1, ty0 .. ty1
+__device__ __forceinline__ TRect tile_rect_of(uint32_t tx0, uint32_t ty0, uint32_t wx, uint32_t ty1, uint32_t shard_rank, uint32_t shard_world) {
+    TRect r{ tx0, ty0, wx, ty1 - ty0 + 1u, 1u, 0u };
     if (shard_world > 1u) {
         const uint32_t first = r.ty0 + (shard_rank + shard_world - r.ty0 % shard_world) % shard_world;
         r.rows = first > ty1 ? 0u : (ty1 - first) / shard_world + 1u;
@@ -164,6 +160,29 @@ __device__ __forceinline__ TRect tile_rect(uint32_t rect0, uint32_t rect1, uint3
     }
     r.count = r.wx * r.rows;
     return r;
+}
+__device__ __forceinline__ TRect tile_rect(uint32_t rect0, uint32_t rect1, uint32_t shard_rank, uint32_t shard_world) {
+    const uint32_t x0 = rect0 & 0xFFFFu, y0 = rect0 >> 16, x1 = rect1 & 0xFFFFu, y1 = rect1 >> 16;
+    if (x0 > x1 || y0 > y1) return TRect{ 0u, 0u, 0u, 0u, 1u, 0u };
+    return tile_rect_of(x0 / TILE, y0 / TILE, x1 / TILE - x0 / TILE + 1u, y1 / TILE, shard_rank, shard_world);
+}
+// The per-record input of the list-building kernels: the tile rectangle packed into 4 bytes — tx0:10 | ty0:10 | wx-1:6 | wy-1:6 — read in
+// record order by the scatter (streaming) and in depth order by the binning (a gather: 4 bytes instead of the 8-byte pixel rectangle of
+// rounds 1-2 halves the table).  TRECT_NONE: the record touches no tile.  TRECT_WIDE: more than 63 tiles across or down, or beyond tile
+// 1022 (images wider than 8184 pixels): the consumer takes the pixel rectangle from the projected record (C.z, C.w) instead.
+constexpr uint32_t TRECT_NONE = 0xFFFFFFFFu, TRECT_WIDE = 0xFFFFFFFEu;
+__device__ __forceinline__ uint32_t pack_trect(uint32_t rect0, uint32_t rect1) {
+    const uint32_t x0 = rect0 & 0xFFFFu, y0 = rect0 >> 16, x1 = rect1 & 0xFFFFu, y1 = rect1 >> 16;
+    if (x0 > x1 || y0 > y1) return TRECT_NONE;
+    const uint32_t tx0 = x0 / TILE, ty0 = y0 / TILE, wx = x1 / TILE - tx0, wy = y1 / TILE - ty0;      // widths minus one
+    if (tx0 >= 1023u || ty0 >= 1023u || wx >= 63u || wy >= 63u) return TRECT_WIDE;
+    return tx0 | (ty0 << 10) | (wx << 20) | (wy << 26);
+}
+__device__ __forceinline__ TRect unpack_trect(uint32_t w, const float4* __restrict__ proj, uint32_t rec, uint32_t shard_rank, uint32_t shard_world) {
+    if (w == TRECT_NONE) return TRect{ 0u, 0u, 0u, 0u, 1u, 0u };
+    if (w == TRECT_WIDE) { const float4 c = proj[(size_t)rec * 4 + 2]; return tile_rect(__float_as_uint(c.z), __float_as_uint(c.w), shard_rank, shard_world); }
+    const uint32_t tx0 = w & 1023u, ty0 = (w >> 10) & 1023u;
+    return tile_rect_of(tx0, ty0, ((w >> 20) & 63u) + 1u, ty0 + (w >> 26), shard_rank, shard_world);
 }
 __device__ __forceinline__ uint32_t tile_of(const TRect& r, uint32_t j, uint32_t tiles_x) { return (r.ty0 + (j / r.wx) * r.tstep) * tiles_x + r.tx0 + j % r.wx; }
 // every tile of a small footprint, row by row (no division: this runs once per record in two kernels)
@@ -178,8 +197,8 @@ template <class F> __device__ __forceinline__ void for_each_tile(const TRect& r,
 // (the caller then repacks in the full layout).  Either way plane 0 is pos and soa_sig3() is the plane of sig[3] (what key generation reads).
 hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* n * 96 bytes */, uint32_t* bbox /* [16], preset: min = ~0, max = 0 */, bool compact);
 inline const float4* soa_sig3(const float4* soa, size_t n, bool compact) { return soa + (compact ? 3 : 5) * n; }
-// Each preprocess launch also writes the compact pixel rectangle of every record.
-struct PreOut { float4* proj; uint2* rects; };
+// Each preprocess launch also writes the packed tile rectangle of every record (pack_trect).
+struct PreOut { float4* proj; uint32_t* trects; };
 hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n /* records in the buffer: the plane stride */, bool compact, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
@@ -196,7 +215,8 @@ struct BinScratch {
 hipError_t bin_scratch_reserve(hipStream_t st, BinScratch& b, size_t ninst, size_t ntiles);
 void bin_scratch_free(BinScratch& b);
 // order == nullptr: instance k draws record k
-hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint2* rects, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
+// trects_in_order: trects[k] belongs to INSTANCE k (it travelled through the depth sort as a second payload); else to record k (gathered through `order`)
+hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint32_t* trects, bool trects_in_order, const float4* proj, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int tiles_x, int tiles_y,
                           uint32_t* pair_keys, uint32_t* pair_vals, size_t pair_cap, uint32_t* err, uint32_t* ghist, int passes, uint32_t* total_host, int shard_rank, int shard_world);
 hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pair_keys, size_t pair_cap, size_t ntiles);
 

@@ -162,7 +162,7 @@ __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid,
     // the GL clamps a fragment's colour to [0, 1] before blending into the reference's RGBA8 framebuffer; where the fragment shader passes
     // the colour through unchanged that is a per-record operation (the 3D-Full shader multiplies by c first: clamped per fragment)
     if (clamp_rgb) { r = __saturatef(r); g = __saturatef(g); b = __saturatef(b); }
-    out.rects[i] = make_uint2(rect0, rect1);
+    out.trects[i] = pack_trect(rect0, rect1);
     float4* o = out.proj + (size_t)i * 4;
     // (x components of the two affine rows side by side, likewise y: the compositor forms u and v with packed two-float instructions)
     o[0] = make_float4(cx, cy, a0x, a1x);

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict_
 }
 
 // Segment w again: every entry goes to tmp[bucket start + slot of run (w, bucket) + a counter in LDS].  SEG_THREADS threads, one record each per round.
-__global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter(const uint2* __restrict__ rects, const uint32_t* __restrict__ skey, uint32_t skey_bias, uint32_t n, uint32_t seg, uint32_t nb,
+__global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter(const uint32_t* __restrict__ trects, const float4* __restrict__ proj, const uint32_t* __restrict__ skey, uint32_t skey_bias, uint32_t n, uint32_t seg, uint32_t nb,
                                                         const uint32_t* __restrict__ offs, const uint32_t* __restrict__ bbase, const uint32_t* __restrict__ total, uint2* __restrict__ tmp,
                                                         uint32_t tiles_x, uint32_t shard_rank, uint32_t shard_world) {
     __shared__ uint32_t cur[1024];
@@ -119,17 +119,17 @@ __global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter(const uint2* __r
     const uint32_t i0 = blockIdx.x * seg, i1 = min(n, i0 + seg);
     constexpr int SC_ITEMS = 4;                            // records per thread and round: all their loads are in flight before the first LDS atomic
     for (uint32_t ib = i0; ib < i1; ib += SEG_THREADS * SC_ITEMS) {      // uniform trip count: every lane stays to the end
-        uint2 rc[SC_ITEMS]; uint32_t kk[SC_ITEMS];
+        uint32_t rc[SC_ITEMS], kk[SC_ITEMS];
 #pragma unroll
         for (int q = 0; q < SC_ITEMS; ++q) {
             const uint32_t i = ib + (uint32_t)q * SEG_THREADS + tid;
-            rc[q] = i < i1 ? rects[i] : make_uint2(1u, 0u);
+            rc[q] = i < i1 ? trects[i] : TRECT_NONE;
             kk[q] = i < i1 ? skey[i] - skey_bias : 0u;                        // (a draw that generated the depth keys itself reads them where it wrote them: the caller's key buffer, bit patterns above the bias)
         }
 #pragma unroll
         for (int q = 0; q < SC_ITEMS; ++q) {
             const uint32_t i = ib + (uint32_t)q * SEG_THREADS + tid;
-            const TRect r = tile_rect(rc[q].x, rc[q].y, shard_rank, shard_world);
+            const TRect r = unpack_trect(rc[q], proj, i, shard_rank, shard_world);
             const uint32_t key = kk[q];
             const bool big = r.count > 16u;
             if (!big) for_each_tile(r, tiles_x, [&](uint32_t t) {
@@ -296,8 +296,8 @@ hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uin
     return hipGetLastError();
 }
 
-hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint2* rects, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
-    k_bucket_scatter<<<dim3(t.rows), dim3(SEG_THREADS), 0, st>>>(rects, skey ? skey : t.skey, skey ? skey_bias : 0u, (uint32_t)nrecords, t.seg, t.nb, t.hist + t.hist_cap, t.bbase, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
+hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint32_t* trects, const float4* proj, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world) {
+    k_bucket_scatter<<<dim3(t.rows), dim3(SEG_THREADS), 0, st>>>(trects, proj, skey ? skey : t.skey, skey ? skey_bias : 0u, (uint32_t)nrecords, t.seg, t.nb, t.hist + t.hist_cap, t.bbase, total, tmp, (uint32_t)tiles_x, (uint32_t)shard_rank, (uint32_t)shard_world);
     return hipGetLastError();
 }
 

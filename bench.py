@@ -237,7 +237,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    multi = world > 1
+    multi = world > 1 or os.environ.get("GS4D_BENCH_FORCE_SWEEP") == "1"      # rehearsal on a one-GPU box: the N > 1 program (RCCL gathers, events, two batch buffers) with a communicator of ONE rank
 
     import torch
     import scenes

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Rewrites the kernel tables of profiles/README.md (between the `tables:` markers) from the committed r02 evidence files."""
+"""Rewrites the kernel tables of profiles/README.md (between the `tables:` markers) from the committed evidence files of the current round (TAG)."""
 import csv, json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
+TAG = "r03"
 
 
 def stats(name):
@@ -17,7 +18,7 @@ def line(name):
 
 
 def table(cfg, frames, min_calls):
-    a, o = stats(f"r02_kernel_stats_alone_{cfg}.csv"), stats(f"r02_kernel_stats_{cfg}.csv")
+    a, o = stats(f"{TAG}_kernel_stats_alone_{cfg}.csv"), stats(f"{TAG}_kernel_stats_{cfg}.csv")
     t = f"| kernel, {cfg.upper()}, µs per launch (launches per frame) | alone (1 lane) | overlapped (4 lanes) |\n|---|---|---|\n"
     rows = [k for k in a if a[k][1] >= min_calls]
     for k in rows:
@@ -27,16 +28,16 @@ def table(cfg, frames, min_calls):
 
 
 def traffic(cfg):
-    pm = json.load(open(os.path.join(P, f"r02_pmc_traffic_{cfg}.json")))
+    pm = json.load(open(os.path.join(P, f"{TAG}_pmc_traffic_{cfg}.json")))
     return sum(v["hbm_bytes_per_launch"] * v["launches_per_frame"] for v in pm.values() if v["launches_per_frame"] >= 0.5) / 1e6
 
 
-d, b2, b3 = line("r02_bench_default_driver_settings.json"), line("r02_bench_c2.json"), line("r02_bench_c3.json")
-txt = (f"Driver-style line (`r02_bench_default_driver_settings.json`): C2 {d['ms_per_step']:.4f} ms/frame (windows {d['windows_ms_per_step']}), one lane "
+d, b2, b3 = line(f"{TAG}_bench_default_driver_settings.json"), line(f"{TAG}_bench_c2.json"), line(f"{TAG}_bench_c3.json")
+txt = (f"Driver-style line (`{TAG}_bench_default_driver_settings.json`): C2 {d['ms_per_step']:.4f} ms/frame (windows {d['windows_ms_per_step']}), one lane "
        f"{d['latency_ms_one_lane']:.4f}; C3 {d['c3']['ms_per_step']:.3f} ms/frame, one lane {d['c3']['latency_ms_one_lane']:.3f}. The profiled commands' own lines: "
        f"C2 {b2['ms_per_step']:.4f}, C3 {b3['ms_per_step']:.3f} ms/frame.\n\n" + table("c2", 35, 20) + "\n" + table("c3", 20, 10) +
        f"\nHBM bytes per frame from the counters (kernels launched at least every other frame): C2 {traffic('c2'):.0f} MB = {traffic('c2') / 301.18:.2f} × the algorithmic "
-       f"301 MB (round 1: 623 MB, 2.07 ×); C3 {traffic('c3') / 1e3:.2f} GB = {traffic('c3') / 2713.18:.2f} × 2.71 GB (round 1: 6.48 GB, 2.39 ×).\n")
+       f"301 MB (round 2: 418 MB, 1.39 ×; round 1: 623 MB, 2.07 ×); C3 {traffic('c3') / 1e3:.2f} GB = {traffic('c3') / 2713.18:.2f} × 2.71 GB (round 2: 4.30 GB, 1.58 ×; round 1: 6.48 GB, 2.39 ×).\n")
 path = os.path.join(P, "README.md")
 s = open(path).read()
 s = re.sub(r"<!-- tables:begin -->.*<!-- tables:end -->", "<!-- tables:begin -->\n" + txt + "<!-- tables:end -->", s, flags=re.S)
