@@ -320,3 +320,38 @@ def test_one_key_pair_for_all_frames(gs4d, oracle, monkeypatch, rename):
     ctx.finish()
     assert ctx.device_ptr(kb)[0] == p0
     ctx.close()
+
+
+@pytest.mark.parametrize("path", ["auto", "ordered"])
+def test_tile_rectangles_beyond_the_packed_range(gs4d, oracle, monkeypatch, path):
+    """The list-building kernels read a 4-byte packed tile rectangle per record (10 bits per tile coordinate, 6 per extent).  A frame wider
+    than 8184 pixels has tiles beyond 1022, and a close-up splat spans more than 63 tiles: both take the escape route (the pixel
+    rectangle of the projected record).  Same picture as the checker's on both list paths."""
+    if path == "ordered":
+        monkeypatch.setenv("GS4D_DRAW_PATH", "ordered")
+    else:
+        monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    W, H = 8400, 96
+    cam = ((0.0, 0.0, 40.0), (0.0, 0.0, -1.0))
+    view, proj = cam_mats(gs4d, cam, W, H)
+    n = 4000
+    pos, q, sc, rgba = scenes.cube_params(n, seed=81)
+    pos[:, 0] *= 10.0                                            # spread across the very wide frame (x in +-2000 at depth 40..: most of it visible)
+    pos[:, 1] *= 0.02
+    pos[:, 2] *= 0.05
+    sc *= 6.0
+    sc[:8] *= 40.0                                               # a few huge ones: hundreds of tiles across
+    rgba[:, 3] *= 0.5
+    rec = gs4d.build_records_3d(pos, q, sc, rgba)
+    ctx = gs4d.Context(W, H)
+    from test_gpu_render import gpu_frame
+    img, projd, st, _ = gpu_frame(ctx, gs4d, rec, cam)
+    ctx.close()
+    eimg, _, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    x0 = (projd[:, 10].copy().view(np.uint32) & 0xFFFF).astype(np.int64)
+    x1 = (projd[:, 11].copy().view(np.uint32) & 0xFFFF).astype(np.int64)
+    drawn = (projd[:, 14] != 0) & (x0 <= x1)
+    assert (x0[drawn] // 8 >= 1023).any()                        # rectangles that start beyond the packed range
+    assert ((x1[drawn] // 8 - x0[drawn] // 8) >= 63).any()       # ... and that are wider than it holds
+    assert linf(img, eimg) <= TOL
+    assert np.abs(eimg[:, 8184:] - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.05      # something is drawn out there
