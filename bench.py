@@ -190,11 +190,16 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
     cred = [k for k, v in warm_ms.items() if v > 0 and alg[k] > 0]
     dominant = max(cred, key=lambda k: warm_ms[k]) if cred else None
     ctx.set_profiling([dominant] if (dominant and stage_events) else False, every=8)
-    aborted_before = ctx.stats()["aborted_discarded"]
-    secs = timed_windows(lambda k: sc.frame(), fence, steps, 0, windows)
-    # frames that aborted on the device (tile-list capacity, list length) and were cleared away before anything observed them are never
-    # re-run: a timed window that contains one has timed an incomplete render.  The library counts them; the bench refuses such a window.
-    aborted = ctx.stats()["aborted_discarded"] - aborted_before
+    # Frames that aborted on the device (tile-list capacity, list length) and were cleared away before anything observed them are never
+    # re-run: a timed window that contains one has timed an incomplete render.  The library counts them; the bench refuses such windows —
+    # once more from the start (the context has learned from the aborted frames by then), and if they still contain one, not at all.
+    for attempt in range(2):
+        aborted_before = ctx.stats()["aborted_discarded"]
+        secs = timed_windows(lambda k: sc.frame(), fence, steps, 0, windows)
+        aborted = ctx.stats()["aborted_discarded"] - aborted_before
+        if not aborted:
+            break
+        print(f"bench.py: {aborted} timed frame(s) aborted on the device and were never completed; timing the windows again", file=sys.stderr)
     if aborted:
         raise RuntimeError(f"{aborted} timed frame(s) aborted on the device and were never completed: the measurement is invalid")
     stage_ms = ctx.timings()
