@@ -35,7 +35,7 @@ def traffic(cfg):
 d, b2, b3 = line(f"{TAG}_bench_default_driver_settings.json"), line(f"{TAG}_bench_c2.json"), line(f"{TAG}_bench_c3.json")
 txt = (f"Driver-style line (`{TAG}_bench_default_driver_settings.json`): C2 {d['ms_per_step']:.4f} ms/frame (windows {d['windows_ms_per_step']}), one lane "
        f"{d['latency_ms_one_lane']:.4f}; C3 {d['c3']['ms_per_step']:.3f} ms/frame, one lane {d['c3']['latency_ms_one_lane']:.3f}. The profiled commands' own lines: "
-       f"C2 {b2['ms_per_step']:.4f}, C3 {b3['ms_per_step']:.3f} ms/frame.\n\n" + table("c2", 35, 20) + "\n" + table("c3", 20, 10) +
+       f"C2 {b2['ms_per_step']:.4f}, C3 {b3['ms_per_step']:.3f} ms/frame.\n\n" + table("c2", 65, 30) + "\n" + table("c3", 29, 12) +
        f"\nHBM bytes per frame from the counters (kernels launched at least every other frame): C2 {traffic('c2'):.0f} MB = {traffic('c2') / 301.18:.2f} × the algorithmic "
        f"301 MB (round 2: 418 MB, 1.39 ×; round 1: 623 MB, 2.07 ×); C3 {traffic('c3') / 1e3:.2f} GB = {traffic('c3') / 2713.18:.2f} × 2.71 GB (round 2: 4.30 GB, 1.58 ×; round 1: 6.48 GB, 2.39 ×).\n")
 path = os.path.join(P, "README.md")
