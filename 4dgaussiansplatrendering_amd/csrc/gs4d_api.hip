@@ -157,7 +157,6 @@ struct gs4d_ctx {
     bool defer_order = true;           // GS4D_FUSE_KEYGEN=0 switches the deferral off (test hook)
     uint64_t stat_fused = 0, stat_renamed = 0;
     bool rename_storage = true;        // GS4D_RENAME=0 switches the storage exchange off (test hook)
-    size_t sort_pay_min = 2000000;     // ordered draws of at least this many records carry the tile rectangles through their depth sort (GS4D_SORT_PAY_MIN: test / tuning hook)
     int shrink_votes = 0;
     // Two ways to get a tile's list into blend order.  Lists of up to V2_MAX_LIST entries: built unordered, ordered by the wave that
     // composites the tile (k_composite_v2).  Longer lists, or a blend order that is not a key the library knows: the instance-ordered path
@@ -479,12 +478,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             // histograms) and the binning (which reads the sorted index)
             Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
             StageTimer t(c, GS4D_T_SORT);
-            // Large draws: the records' packed tile rectangles ride along as a second payload, so that the binning reads them in instance order
-            // instead of gathering them through the sorted index (10^7 random 4-byte reads = 634 MB of memory sectors).  The passes move a third
-            // more bytes; below ~2 M records the gather is served by the caches and the plain sort is the cheaper one.
-            const bool carry = npre >= c->sort_pay_min && a.instances == npre;
-            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true, true, carry ? L.trects : nullptr));
-            L.trects_in_order = carry;
+            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true, true));
         }
     }
     size_t want = a.instances * 2 + 65536;
@@ -641,7 +635,6 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if (const char* ev = getenv("GS4D_FUSE_KEYGEN")) c->defer_order = atoi(ev) != 0;                                       // test hook: 0 = launch key generation and sort at once
     if (const char* ev = getenv("GS4D_DRAW_PATH")) { if (!strcmp(ev, "ordered")) c->path_pref = 1; }
     if (const char* ev = getenv("GS4D_RENAME")) c->rename_storage = atoi(ev) != 0;
-    if (const char* ev = getenv("GS4D_SORT_PAY_MIN")) c->sort_pay_min = (size_t)strtoull(ev, nullptr, 0);
     if (const char* ev = getenv("GS4D_SLABS")) { const int v = atoi(ev); if (v >= 1 && v <= (int)V2_MAX_SLABS) { c->slabs = 1; while ((int)c->slabs < v) c->slabs *= 2u; } }      // test hook: depth slabs (a power of two)                         // test hook: instance-ordered tile lists for every draw
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
     for (int i = 0; i < c->nlanes; ++i) {

@@ -27,7 +27,6 @@ struct Uniforms {
 // ---- sort.hip ----
 struct SortScratch {
     uint32_t* keys2 = nullptr; uint32_t* vals2 = nullptr; size_t cap = 0;   // scratch B and C (keys2[2*cap], vals2[2*cap]; one allocation) — radix_sort.hpp:192-216 scratch
-    uint32_t* pay2 = nullptr; size_t pay2_cap = 0;                          // ... of a second payload (pay2[2*cap]), allocated the first time one is sorted along
     uint32_t* hist = nullptr; size_t hist_cap = 0;                          // two [OS_REPL][4][256] digit-histogram slots (alternating), then the look-back words
     int flip = 0;
     bool hist_pending = false;         // the current slot holds a histogram accumulated by a producer kernel, not yet consumed by a sort
@@ -47,8 +46,7 @@ void sort_scratch_free(SortScratch& s);
 // have_hist: the digit histograms of `keys` were already accumulated (by the kernel that wrote the keys) into sort_hist_slot(s).
 // identity_vals: the payload is the identity index 0..n-1 and `vals` has NOT been written: the first pass that moves keys makes the indices up
 // instead of reading them (4 bytes per key less to write for whoever produced the keys, 4 less to read here).
-// pay2: a second 32-bit payload array (n words) permuted exactly like `vals`, in place (sorted along in 5120-key tiles); n_dev must be null with it.
-hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals = false, uint32_t* pay2 = nullptr);
+hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals = false);
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
 hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
 hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,

@@ -104,7 +104,7 @@ constexpr uint32_t OS_GROUP = 16;         // tiles per look-back group (every lo
 constexpr uint32_t OS_SUPER = 16;         // groups per super-group
 typedef unsigned long long u64;
 
-struct OsBufs { uint32_t* k[3]; uint32_t* v[3]; uint32_t* p[3]; };      // [0] caller's buffers, [1],[2] scratch; p: an optional second 32-bit payload (PAY2 kernels only)
+struct OsBufs { uint32_t* k[3]; uint32_t* v[3]; };      // [0] caller's buffers, [1],[2] scratch
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane) {
 #pragma unroll
@@ -289,9 +289,7 @@ __device__ __forceinline__ uint32_t digit_excl_scan(uint32_t v, uint32_t* tmp /*
 // Persistent workgroups: the grid is what fits the device at once (or one workgroup per tile if that is fewer); a workgroup draws a
 // ticket, sorts that tile, draws the next.  What does not depend on the tile (histograms -> live passes and digit bases, the
 // housekeeping for the next launch) happens once per workgroup, and a finished tile's successor starts without a dispatch.
-// PAY2: a second 32-bit payload travels with every key (the ordered draw path carries each record's packed tile rectangle through its
-// depth sort, so that the binning kernel reads the rectangles in instance order instead of gathering them through the sorted index).
-template <int THREADS, int ITEMS, bool ATOMIC_RANK, bool PAY2 = false>
+template <int THREADS, int ITEMS, bool ATOMIC_RANK>
 __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
                                                      const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
                                                      uint32_t* status /* [tiles][256] */, uint32_t* acc /* [acc_groups + supers][256], zero at launch */, uint32_t* acc_next /* zeroed here */, uint32_t acc_groups, uint32_t acc_words,
@@ -304,7 +302,6 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     static_assert((uint64_t)TILE_KEYS * OS_GROUP * OS_SUPER < (1u << 24) && OS_GROUP < 256u && OS_SUPER < 256u, "accumulators are {arrivals:8, sum:24}");
     __shared__ uint32_t skeys[TILE_KEYS];
     __shared__ uint32_t svals[TILE_KEYS];
-    __shared__ uint32_t spay[PAY2 ? TILE_KEYS : 1];
     __shared__ uint32_t wcnt[WAVES][256];
     __shared__ uint32_t loff[256];      // first local slot of digit d in the reordered tile
     __shared__ uint32_t gpos[256];      // global slot of that first element
@@ -351,7 +348,6 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     const bool make_identity = identity_vals && executed == 0;   // uniform: the first pass that moves keys makes up the payload instead of reading it
     const uint32_t* __restrict__ keys_in = bufs.k[src]; const uint32_t* __restrict__ vals_in = bufs.v[src];
     uint32_t* __restrict__ keys_out = bufs.k[dst]; uint32_t* __restrict__ vals_out = bufs.v[dst];
-    const uint32_t* __restrict__ pay_in = PAY2 ? bufs.p[src] : nullptr; uint32_t* __restrict__ pay_out = PAY2 ? bufs.p[dst] : nullptr;
     uint32_t digit_base = 0;
     bool first = true;
     const uint32_t ngroups = (ntiles + OS_GROUP - 1u) / OS_GROUP, nsuper = (ngroups + OS_SUPER - 1u) / OS_SUPER;
@@ -360,14 +356,13 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         OS_STAMP(0);
         const uint32_t tbase = tile * TILE_KEYS;
         const uint32_t wbase = tbase + w * (64u * ITEMS);
-        uint32_t key[ITEMS], val[ITEMS], rank[ITEMS], pay[PAY2 ? ITEMS : 1];
+        uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const uint32_t i = wbase + j * 64u + lane;
             const bool valid = i < n;
             key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
             val[j] = !valid ? 0u : make_identity ? i : vals_in[i];
-            if (PAY2) pay[j] = valid ? pay_in[i] : 0u;
         }
         if (first) { digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid); first = false; }      // once per workgroup, under the first tile's loads
         OS_STAMP(1);
@@ -433,7 +428,6 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
                 const uint32_t l = loff[d] + wcnt[w][d] + rank[j];
                 skeys[l] = key[j];
                 svals[l] = val[j];
-                if (PAY2) spay[l] = pay[j];
             }
         }
         OS_STAMP(3);
@@ -466,8 +460,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
                 // without gs4d_buffer_invalidate — the two no longer describe the same array and `o` can point anywhere.  One compare keeps
                 // the store inside the buffer and turns the contract violation into the error word (the frame is reported as failed).
                 if (o >= n) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); continue; }
-                if (PAY2) pay_out[o] = spay[l];
-                if (ITEMS >= 10) { keys_out[o] = k; vals_out[o] = svals[l]; }
+                if (ITEMS >= 16) { keys_out[o] = k; vals_out[o] = svals[l]; }
                 else { __builtin_nontemporal_store(k, keys_out + o); __builtin_nontemporal_store(svals[l], vals_out + o); }
             }
         }
@@ -562,7 +555,6 @@ hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n) {
 
 void sort_scratch_free(SortScratch& s) {
     if (s.keys2) (void)hipFree(s.keys2);
-    if (s.pay2) (void)hipFree(s.pay2);
     if (s.hist) (void)hipFree(s.hist);
     if (s.totals) (void)hipFree(s.totals);
     s = SortScratch();
@@ -579,15 +571,15 @@ uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError
     return s.hist + (s.flip ? OS_SLOT_WORDS : 0);
 }
 
-template <int THREADS, int ITEMS, bool ATOMIC_RANK, bool PAY2 = false>
-static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist, bool identity_vals, uint32_t* pay2 = nullptr) {
+template <int THREADS, int ITEMS, bool ATOMIC_RANK>
+static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist, bool identity_vals) {
     const uint32_t tile_keys = THREADS * ITEMS;
     const uint32_t tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
     // persistent workgroups: as many as the device holds at once (asked of the runtime once per shape)
     static uint32_t resident = 0;
     if (!resident) {
         int per_cu = 0, dev = 0; hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_os_pass<THREADS, ITEMS, ATOMIC_RANK, PAY2>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_os_pass<THREADS, ITEMS, ATOMIC_RANK>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
         resident = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
     }
@@ -621,14 +613,13 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     b.k[0] = keys; b.v[0] = vals;
     b.k[1] = s.keys2; b.v[1] = s.vals2;
     b.k[2] = s.keys2 + s.cap; b.v[2] = s.vals2 + s.cap;
-    b.p[0] = pay2; b.p[1] = PAY2 ? s.pay2 : nullptr; b.p[2] = PAY2 ? s.pay2 + s.cap : nullptr;
     for (int p = 0; p < passes; ++p) {
         ++s.epoch;
         if ((s.epoch & 0x3FFFFu) == 0u) {    // the 18-bit tile-level epoch wraps: forget every old word
             if ((e = hipMemsetAsync(status, 0, (s.hist_cap - 2 * OS_SLOT_WORDS) * 4, st)) != hipSuccess) return e;
             ++s.epoch;
         }
-        k_os_pass<THREADS, ITEMS, ATOMIC_RANK, PAY2><<<dim3(grid), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, acc_base + (s.acc_flip ? acc_words : 0), acc_base + (s.acc_flip ? 0 : acc_words), (uint32_t)cap_groups, (uint32_t)acc_words,
+        k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(grid), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, acc_base + (s.acc_flip ? acc_words : 0), acc_base + (s.acc_flip ? 0 : acc_words), (uint32_t)cap_groups, (uint32_t)acc_words,
                                                                          s.epoch & 0x3FFFFFFFu,
                                                                          s.err ? s.err : s.totals, s.totals + 64 + (s.acc_flip ? 1 : 0), s.totals + 64 + (s.acc_flip ? 0 : 1), bias, identity_vals ? 1 : 0, (stampf && p == stamp_pass) ? stamps : nullptr);
         s.acc_flip ^= 1;
@@ -644,17 +635,11 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     return hipGetLastError();
 }
 
-hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals, uint32_t* pay2) {
+hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals) {
     if (n <= 1) { if (n == 1 && identity_vals) return hipMemsetAsync(vals, 0, 4, st); return hipSuccess; }      // radix_sort.hpp:260
     if (n >= (1ull << 32) - 1) return hipErrorInvalidValue;
     hipError_t e = sort_scratch_reserve(st, s, n);
     if (e != hipSuccess) return e;
-    if (pay2 && s.pay2_cap < s.cap) {                 // scratch B and C of the second payload, on first use
-        if (s.pay2) { (void)hipStreamSynchronize(st); (void)hipFree(s.pay2); }
-        s.pay2 = nullptr; s.pay2_cap = 0;
-        if ((e = hipMalloc(&s.pay2, s.cap * 8)) != hipSuccess) return e;
-        s.pay2_cap = s.cap;
-    }
     int passes = (key_bits + 7) / 8;
     if (passes < 2) passes = 2;                       // an even number of executed passes always exists (see os_schedule)
     // 8192-key tiles: 1024 threads x 8 keys (streaming stores) for small sorts, 512 x 16 (ordinary stores) beyond 1.5M keys.  Alone, a pass over
@@ -664,9 +649,6 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
     const int shape = s.shape_knob ? s.shape_knob : (n <= ((size_t)3 << 19) ? 3 : 5);
     const bool atomic_rank = s.rank_knob ? s.rank_knob == 2 : s.atomic_rank;
 #define GS4D_OS(T, I) (atomic_rank ? onesweep<T, I, true>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals) : onesweep<T, I, false>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals))
-    // the second payload: 5120-key tiles (512 x 10: three 20 KB planes in LDS, two workgroups per CU as without it)
-    if (pay2) return atomic_rank ? onesweep<512, 10, true, true>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals, pay2)
-                                 : onesweep<512, 10, false, true>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals, pay2);
     switch (shape) {
     case 1: return GS4D_OS(256, 8);
     case 2: return GS4D_OS(512, 8);

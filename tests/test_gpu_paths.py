@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _ctx(gs4d, W, H, monkeypatch, **env):
-    for k in ("GS4D_DRAW_PATH", "GS4D_SORT_RANK", "GS4D_SORT_SHAPE", "GS4D_SLABS", "GS4D_SORT_PAY_MIN"):
+    for k in ("GS4D_DRAW_PATH", "GS4D_SORT_RANK", "GS4D_SORT_SHAPE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
@@ -157,49 +157,6 @@ def test_depth_slabs(gs4d, oracle, monkeypatch, slabs):
     ctx.close()
     eimg2, eperm2, _ = oracle.render_4d(rec2, True, 0.0, 0.0, cam2[0], view2, proj2, W, H)
     assert np.array_equal(perm2, eperm2) and linf(img2, eimg2) <= TOL and st2["tile_sort_passes"] >= 2
-
-
-@pytest.mark.parametrize("n,W,H,scale", [(200000, 1920, 1080, 1.0), (30000, 640, 360, 4.0), (5121, 320, 200, 6.0)])
-def test_tile_rectangles_carried_through_the_depth_sort(gs4d, oracle, monkeypatch, n, W, H, scale):
-    """The instance-ordered path of a draw that generates its own keys: from GS4D_SORT_PAY_MIN records on, the packed tile rectangles ride
-    through the depth sort as a second payload (5120-key tiles) and the binning reads them in instance order.  Same permutation, same keys,
-    same frame — bit for bit — as with the rectangles gathered through the sorted index; duplicated keys and a one-key-more-than-a-tile
-    size included."""
-    pos, q, sc, rgba = scenes.cube_params(n, seed=47)
-    if n == 30000:
-        pos = np.repeat(pos[: n // 3], 3, 0)                                      # keys tie in threes
-    rec = gs4d.build_records_3d(pos, q, sc * scale, rgba)
-    cam = scenes.CAM_CUBE
-    view, proj = cam_mats(gs4d, cam, W, H)
-    eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
-    imgs = {}
-
-    def frame(ctx, db, kb, ib):
-        """keygen -> sort -> draw back to back (nothing looks at the key buffers in between): the draw executes all three"""
-        ctx.clear()
-        ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
-        ctx.keygen(db, 0.0, cam[0], kb, ib, n)
-        ctx.sort_pairs(kb, ib, n)
-        ctx.bind(1, ib)
-        ctx.bind(2, db)
-        ctx.draw_instanced(n)
-        return ctx.read_pixels(), ctx.read(ib, np.uint32, n)
-    for carry in (True, False):
-        ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_DRAW_PATH="ordered", GS4D_SORT_PAY_MIN=0 if carry else 1 << 40)
-        ctx.set_clear_color(gs4d.CLEAR_COLOR)
-        ctx.set_mode(gs4d.MODE_4D_SORTED)
-        db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
-        img, perm = frame(ctx, db, kb, ib)
-        img2, perm2 = frame(ctx, db, kb, ib)                    # again: the second payload's scratch is reused, another lane
-        st = ctx.stats()
-        ctx.close()
-        assert np.array_equal(perm, eperm) and np.array_equal(perm2, eperm)
-        assert linf(img, eimg) <= TOL
-        assert np.array_equal(img, img2)
-        assert st["tile_sort_passes"] >= 2 and st["fused_keygen_draws"] == 2
-        imgs[carry] = img
-    assert np.array_equal(imgs[True], imgs[False])
-    monkeypatch.delenv("GS4D_SORT_PAY_MIN", raising=False)
 
 
 def test_long_lists_in_a_dense_cloud(gs4d, oracle, monkeypatch):
