@@ -491,6 +491,10 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             // waits for it (the draw took its order from the keys), it fills the caller's buffers for whoever reads them next
             Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
             StageTimer t(c, GS4D_T_SORT);
+#ifdef GS4D_TUNING
+            static const bool skip_sort = getenv("GS4D_ABLATE_SORT") != nullptr;      // ablation (make TUNING=1): what the frame costs without its depth sort — an upper bound for any re-scheduling of it
+            if (skip_sort) { L.depth_sort.hist_pending = false; L.depth_sort.flip ^= 1; return rc; }
+#endif
             HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true, true));
         }
         return rc;
