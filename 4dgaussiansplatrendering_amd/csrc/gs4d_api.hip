@@ -368,6 +368,9 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
         HIPCHK(c, launch_bucket_tiles(L.s, L.tl, ntiles, L.bin.total, tmp, entries, c->list_hint));
     }
     c->stat_tile_passes = 0;
+#ifdef GS4D_TUNING
+    { static const bool skip = getenv("GS4D_ABLATE_COMPOSITE") != nullptr; if (skip) { HIPCHK(c, hipEventRecord(L.ev_emit, L.s)); return GS4D_OK; } }      // ablation: the frame without its compositing kernel (steady state only: the verdict words keep their last values)
+#endif
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
         HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem,

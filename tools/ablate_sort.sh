@@ -4,5 +4,8 @@ run GS4D_LANES=4
 run GS4D_LANES=4 GS4D_ABLATE_SORT=1
 run GS4D_LANES=4
 run GS4D_LANES=4 GS4D_ABLATE_SORT=1
+run GS4D_LANES=4 GS4D_ABLATE_COMPOSITE=1
+run GS4D_LANES=4 GS4D_ABLATE_COMPOSITE=1 GS4D_ABLATE_SORT=1
 run GS4D_LANES=1
 run GS4D_LANES=1 GS4D_ABLATE_SORT=1
+run GS4D_LANES=1 GS4D_ABLATE_COMPOSITE=1
