@@ -20,51 +20,69 @@
 
 namespace gs4d {
 
-__global__ __launch_bounds__(256) void k_fill(float4* __restrict__ fb, uint32_t npix, float4 c) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < npix) fb[i] = c;
+// ---- framebuffer tile state ("fast clear") -----------------------------------------------------------------------------------------
+// tstate[tile] == epoch  <=>  the tile's 64 pixels are in memory.  Any other value: the tile is still the clear colour of the
+// gs4d_clear that started the frame (each clear of an image takes a new epoch: no memset).  The compositing kernels write only the
+// tiles that have list entries — at 1080p three tiles in four of the cube scenes have none — and everything that reads an image
+// substitutes the clear colour for the others (the RGBA8 packs) or writes it first (k_fill_unwritten: host read-backs, float copies,
+// overlay lines, which touch single pixels).  It is what a GL driver's fast clear does with glClear.
+
+// one wave per tile: tiles whose pixels are not in memory get the clear colour
+__global__ __launch_bounds__(64) void k_fill_unwritten(float4* __restrict__ fb, uint32_t* __restrict__ tstate, uint32_t epoch, float4 c, int tiles_x, int W, int H) {
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    if (tstate[tile] == epoch) return;                      // uniform
+    const int px = (int)(tile % (uint32_t)tiles_x) * TILE + (int)(lane & 7u), py = (int)(tile / (uint32_t)tiles_x) * TILE + (int)(lane >> 3);
+    if (px < W && py < H) fb[(size_t)py * W + px] = c;
+    if (lane == 0u) tstate[tile] = epoch;
 }
 
-hipError_t launch_fill(hipStream_t st, float4* fb, size_t npix, const float clear[4]) {
-    k_fill<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st>>>(fb, (uint32_t)npix, make_float4(clear[0], clear[1], clear[2], clear[3]));
+hipError_t launch_fill_unwritten(hipStream_t st, float4* fb, uint32_t* tstate, uint32_t epoch, int tiles_x, int tiles_y, int W, int H, const float clear[4]) {
+    k_fill_unwritten<<<dim3((unsigned)(tiles_x * tiles_y)), dim3(64), 0, st>>>(fb, tstate, epoch, make_float4(clear[0], clear[1], clear[2], clear[3]), tiles_x, W, H);
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void k_pack_rgba8(const float4* __restrict__ fb, uint32_t npix, uint32_t* __restrict__ out) {
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= npix) return;
-    float4 v = fb[i];
+__device__ __forceinline__ uint32_t pack8(float4 v) {
     auto q = [](float x) { return (uint32_t)__float2int_rn(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f); };
-    out[i] = q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
+    return q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
 }
 
-hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, size_t npix, uint32_t* out) {
-    k_pack_rgba8<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st>>>(fb, (uint32_t)npix, out);
+__global__ __launch_bounds__(256) void k_pack_rgba8(const float4* __restrict__ fb, const uint32_t* __restrict__ tstate, uint32_t epoch, float4 c, uint32_t W, uint32_t npix, uint32_t tiles_x, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= npix) return;
+    const uint32_t x = i % W, y = i / W;
+    const bool have = tstate[(y / (uint32_t)TILE) * tiles_x + x / (uint32_t)TILE] == epoch;
+    out[i] = pack8(have ? fb[i] : c);
+}
+
+hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, const uint32_t* tstate, uint32_t epoch, const float clear[4], int W, int H, int tiles_x, uint32_t* out) {
+    const size_t npix = (size_t)W * H;
+    k_pack_rgba8<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st>>>(fb, tstate, epoch, make_float4(clear[0], clear[1], clear[2], clear[3]), (uint32_t)W, (uint32_t)npix, (uint32_t)tiles_x, out);
     return hipGetLastError();
 }
 
 // Band of a tile-row-sharded frame: output row b belongs to the context's (b / TILE)-th tile row, i.e. tile row rank + (b / TILE) * world.
-__global__ __launch_bounds__(256) void k_pack_rgba8_band(const float4* __restrict__ fb, uint32_t W, uint32_t H, uint32_t rank, uint32_t world, uint32_t band_rows, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_pack_rgba8_band(const float4* __restrict__ fb, const uint32_t* __restrict__ tstate, uint32_t epoch, float4 c, uint32_t W, uint32_t H, uint32_t tiles_x,
+                                                         uint32_t rank, uint32_t world, uint32_t band_rows, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= band_rows * W) return;
     const uint32_t b = i / W, x = i % W;
-    const uint32_t y = (rank + (b / (uint32_t)TILE) * world) * (uint32_t)TILE + b % (uint32_t)TILE;
+    const uint32_t ty = rank + (b / (uint32_t)TILE) * world;
+    const uint32_t y = ty * (uint32_t)TILE + b % (uint32_t)TILE;
     if (y >= H) return;                                    // cannot happen for a band_rows computed by band_pixel_rows(); kept as a guard
-    const float4 v = fb[(size_t)y * W + x];
-    auto q = [](float f) { return (uint32_t)__float2int_rn(fminf(fmaxf(f, 0.0f), 1.0f) * 255.0f); };
-    out[i] = q(v.x) | (q(v.y) << 8) | (q(v.z) << 16) | (q(v.w) << 24);
+    const bool have = tstate[ty * tiles_x + x / (uint32_t)TILE] == epoch;
+    out[i] = pack8(have ? fb[(size_t)y * W + x] : c);
 }
 
-hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, int W, int H, int rank, int world, int band_rows, uint32_t* out) {
+hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, const uint32_t* tstate, uint32_t epoch, const float clear[4], int W, int H, int tiles_x, int rank, int world, int band_rows, uint32_t* out) {
     if (band_rows <= 0) return hipSuccess;
     const size_t n = (size_t)band_rows * W;
-    k_pack_rgba8_band<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(fb, (uint32_t)W, (uint32_t)H, (uint32_t)rank, (uint32_t)world, (uint32_t)band_rows, out);
+    k_pack_rgba8_band<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(fb, tstate, epoch, make_float4(clear[0], clear[1], clear[2], clear[3]), (uint32_t)W, (uint32_t)H, (uint32_t)tiles_x, (uint32_t)rank, (uint32_t)world, (uint32_t)band_rows, out);
     return hipGetLastError();
 }
 
 template <bool PREMULT_C, bool GENERAL>
 __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ proj, const uint32_t* __restrict__ pair_vals, uint32_t* __restrict__ ranges,
-                                                  const uint32_t* __restrict__ total, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
+                                                  const uint32_t* __restrict__ total, int tiles_x, int W, int H, uint32_t* __restrict__ tstate, uint32_t epoch, float4 clear,
                                                   float4* __restrict__ fb, int dbg_arg, BlendFn bf) {
 #ifdef GS4D_TUNING
     const int dbg = dbg_arg;             // GS4D_COMPOSITE_DBG: tuning builds only (make TUNING=1)
@@ -82,6 +100,8 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     const uint32_t start = ranges[2 * tile], end = ranges[2 * tile + 1];
     if (lane < 2u && end != 0u) ranges[2 * tile + lane] = 0u;      // leave the table all-zero for the next draw (no memset launch)
+    if (start >= end) return;                               // uniform: nothing is drawn on this tile — its pixels, or its being clear, stay as they are
+    const bool fb_is_clear = tstate[tile] != epoch;         // uniform: the tile's pixels are not in memory yet
 
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
     if (GENERAL) {
@@ -96,6 +116,7 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
             composite_chunk<PREMULT_C, true>(proj, rec, cnt, lane, tx0, ty0, fx, fy, stage, pmask, dbg, T, Cr, Cg, Cb, A, bf);
         }
         if (in) fb[o] = make_float4(Cr, Cg, Cb, A);
+        if (lane == 0u) tstate[tile] = epoch;
         return;
     }
     for (uint32_t hi = end; hi > start;) {
@@ -111,10 +132,11 @@ __global__ __launch_bounds__(64) void k_composite(const float4* __restrict__ pro
         const float4 d = fb_is_clear ? clear : fb[o];
         fb[o] = make_float4(Cr + T * d.x, Cg + T * d.y, Cb + T * d.z, A + T * d.w);
     }
+    if (lane == 0u) tstate[tile] = epoch;
 }
 
 hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
-                            int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb, int blend_src, int blend_dst) {
+                            int W, int H, int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, int blend_src, int blend_dst) {
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid(composite_grid(tiles_x, tiles_y));
 #ifdef GS4D_TUNING
@@ -125,11 +147,11 @@ hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* 
     const BlendFn bf{ blend_src, blend_dst };
     const bool general = !(blend_src == GS4D_SRC_ALPHA && blend_dst == GS4D_ONE_MINUS_SRC_ALPHA);
     if (general) {
-        if (premult_c) k_composite<true, true><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg, bf);
-        else           k_composite<false, true><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg, bf);
+        if (premult_c) k_composite<true, true><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, tstate, epoch, c, fb, dbg, bf);
+        else           k_composite<false, true><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, tstate, epoch, c, fb, dbg, bf);
     }
-    else if (premult_c) k_composite<true, false><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg, bf);
-    else                k_composite<false, false><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, fb_is_clear, c, fb, dbg, bf);
+    else if (premult_c) k_composite<true, false><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, tstate, epoch, c, fb, dbg, bf);
+    else                k_composite<false, false><<<grid, dim3(64), 0, st>>>(proj, pair_vals, ranges, total, tiles_x, W, H, tstate, epoch, c, fb, dbg, bf);
     return hipGetLastError();
 }
 

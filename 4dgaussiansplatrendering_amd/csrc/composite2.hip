@@ -60,7 +60,7 @@ struct WaveSort {
 
 template <bool PREMULT_C, int PER>
 __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
-                                                     const uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, int tiles_x, int W, int H, int fb_is_clear, float4 clear,
+                                                     const uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, int tiles_x, int W, int H, uint32_t* __restrict__ tstate, uint32_t epoch, float4 clear,
                                                      float4* __restrict__ fb, int key_passes, int rec_passes, uint32_t slabs) {
     // the sort's key plane and the blend's record staging never live at the same time: one piece of LDS serves both
     constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
@@ -84,6 +84,8 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     // the tile's list is `slabs` sub-lists by the top bits of the key; larger key = nearer: the last slab is blended first
     uint32_t my_start = 0u, my_cnt = 0u;                    // lane s: sub-list s of this tile (one load for the whole table row)
     if (lane < slabs) { my_start = tstart[(size_t)tile * slabs + lane]; my_cnt = tcnt[(size_t)tile * slabs + lane]; }
+    if (__ballot(my_cnt != 0u) == 0ull) return;             // nothing is drawn on this tile: its pixels, or its being clear (composite.hip: tile state), stay as they are
+    const bool fb_is_clear = tstate[tile] != epoch;         // uniform: the tile's pixels are not in memory yet
     for (int sb = (int)slabs - 1; sb >= 0; --sb) {
         const uint32_t start = __shfl(my_start, sb, 64);
         const uint32_t E = min((uint32_t)__shfl(my_cnt, sb, 64), (uint32_t)(64 * PER));         // k_bucket_tiles guarantees the bound; min() keeps a broken promise inside LDS
@@ -129,12 +131,13 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
         const float4 d = fb_is_clear ? clear : fb[o];
         fb[o] = make_float4(Cr + T * d.x, Cg + T * d.y, Cb + T * d.z, A + T * d.w);
     }
+    if (lane == 0u) tstate[tile] = epoch;
 }
 
 template <bool PREMULT_C>
 static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int W, int H,
-                            int fb_is_clear, float4 c, float4* fb, int kp, int rp, uint32_t slabs) {
-#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
+                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs) {
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs)
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
@@ -150,14 +153,14 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
 }
 
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
-                               int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs) {
+                               int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs) {
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid(composite_grid(tiles_x, tiles_y));
     const int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
-    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs)
-                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, fb_is_clear, c, fb, kp, rp, slabs);
+    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs)
+                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs);
 }
 
 } // namespace gs4d

@@ -63,7 +63,6 @@ struct DrawArgs {
     gs4d_buf data = 0, order = 0;
     size_t instances = 0;
     bool quads = false;
-    bool fb_was_clear = false;     // framebuffer state the composite of this draw must start from (kept for a re-run)
     int lane = 0, fb = 0;          // where the draw ran
     bool v2 = false;               // unordered tile lists (tilelist.hip); false: instance-ordered lists (binning.hip)
     KeySrc ks; int keybits = 32;   // v2: where the blend order comes from
@@ -82,8 +81,12 @@ struct DrawArgs {
 struct Framebuffer {
     float4* mem = nullptr;
     uint32_t* linecnt = nullptr;   // per-pixel fragment counters of the overlay-line kernels (lines.hip), allocated on first use, all-zero between calls
-    bool is_clear = true;          // content == clear colour, not yet materialised
-    float clear[4] = { 0, 0, 0, 0 };   // that colour: the context's clear colour at the gs4d_clear that cleared this image
+    bool is_clear = true;          // no draw has touched the image since its gs4d_clear
+    // Tile state ("fast clear", composite.hip): tstate[tile] == epoch <=> the tile's pixels are in memory; any other tile is still the clear
+    // colour.  gs4d_clear takes a new epoch (no memset, no fill); the compositing kernels write the tiles that have list entries; readers
+    // substitute the clear colour (RGBA8 packs) or have the rest written first (materialise_fb: host read-backs, float copies, overlay lines).
+    uint32_t* tstate = nullptr; uint32_t epoch = 1; bool all_in_memory = false;
+    float clear[4] = { 0, 0, 0, 0 };   // the clear colour: the context's at the gs4d_clear that cleared this image
     int last_lane = -1;            // lane that touched it last
 };
 
@@ -315,11 +318,13 @@ int fb_access(gs4d_ctx* c, Framebuffer& F) {
     return GS4D_OK;
 }
 
+// every tile of the current image into memory (the lazily clear ones get their clear colour): for whoever reads or writes single pixels
 int materialise_fb(gs4d_ctx* c) {
     Framebuffer& F = c->fbs[c->cur_fb];
-    if (F.is_clear) {
+    if (!F.all_in_memory) {
         int rc = fb_access(c, F); if (rc) return rc;
-        HIPCHK(c, launch_fill(lane(c).s, F.mem, (size_t)c->W * c->H, F.clear));
+        HIPCHK(c, launch_fill_unwritten(lane(c).s, F.mem, F.tstate, F.epoch, c->tiles_x, c->tiles_y, c->W, c->H, F.clear));
+        F.all_in_memory = true;
         F.is_clear = false;
     }
     return GS4D_OK;
@@ -327,7 +332,7 @@ int materialise_fb(gs4d_ctx* c) {
 
 // Enqueue binning -> tile sort -> ranges -> composite for the projected records in L.proj.
 int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, const uint32_t* order, uint32_t* order_copy, size_t ninst, size_t nrecords, int premult_c) {
-    const bool fb_was_clear = a.fb_was_clear; const int blend_src = a.blend_src, blend_dst = a.blend_dst;
+    const int blend_src = a.blend_src, blend_dst = a.blend_dst;
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
@@ -348,7 +353,7 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, cons
     {
         StageTimer t(c, GS4D_T_COMPOSITE);      // the per-tile ranges and the compositing kernel
         HIPCHK(c, launch_tile_ranges(L.s, L.bin, L.pair_keys, L.pair_cap, ntiles));
-        HIPCHK(c, launch_composite(L.s, L.proj, L.pair_vals, L.bin.ranges, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, fb_was_clear ? 1 : 0, a.clear, F.mem, blend_src, blend_dst));
+        HIPCHK(c, launch_composite(L.s, L.proj, L.pair_vals, L.bin.ranges, L.bin.total, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, F.tstate, F.epoch, a.clear, F.mem, blend_src, blend_dst));
     }
     return GS4D_OK;
 }
@@ -373,7 +378,7 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
 #endif
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
-        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, a.fb_was_clear ? 1 : 0, a.clear, F.mem,
+        HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, F.tstate, F.epoch, a.clear, F.mem,
                                       c->list_hint, a.keybits, recbits, L.tl.slabs));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event (the compositor's first workgroup wrote them)
@@ -607,8 +612,13 @@ int alloc_fbs(gs4d_ctx* c, int w, int h) {
     { int rc = sync_all(c); if (rc) return rc; }
     for (int i = 0; i < c->nlanes; ++i) {
         if (c->fbs[i].mem) { (void)hipFree(c->fbs[i].mem); c->fbs[i].mem = nullptr; }
+        if (c->fbs[i].tstate) { (void)hipFree(c->fbs[i].tstate); c->fbs[i].tstate = nullptr; }
         if (c->fbs[i].linecnt) { (void)hipFree(c->fbs[i].linecnt); c->fbs[i].linecnt = nullptr; }
         HIPCHK(c, hipMalloc(&c->fbs[i].mem, (size_t)w * h * 16));
+        const size_t nt = (size_t)((w + TILE - 1) / TILE) * ((h + TILE - 1) / TILE);
+        HIPCHK(c, hipMalloc(&c->fbs[i].tstate, nt * 4));
+        HIPCHK(c, hipMemset(c->fbs[i].tstate, 0, nt * 4));      // no tile is in memory: epochs start at 1
+        c->fbs[i].epoch = 1; c->fbs[i].all_in_memory = false;
         c->fbs[i].is_clear = true; c->fbs[i].last_lane = -1; memcpy(c->fbs[i].clear, c->clear, 16);
     }
     c->W = w; c->H = h; c->tiles_x = (w + TILE - 1) / TILE; c->tiles_y = (h + TILE - 1) / TILE;
@@ -678,6 +688,7 @@ void gs4d_destroy(gs4d_ctx* c) {
     for (int i = 0; i < MAX_LANES; ++i) {
         Lane& L = c->lanes[i];
         if (c->fbs[i].mem) (void)hipFree(c->fbs[i].mem);
+        if (c->fbs[i].tstate) (void)hipFree(c->fbs[i].tstate);
         if (c->fbs[i].linecnt) (void)hipFree(c->fbs[i].linecnt);
         if (L.line_verts) (void)hipFree(L.line_verts);
         if (L.order_copy) (void)hipFree(L.order_copy);
@@ -857,7 +868,14 @@ int gs4d_clear(gs4d_ctx* c) {
     if (c->cur != c->cur_fb) c->prev_fb = c->cur_fb;
     else if (c->nlanes == 1) c->prev_fb = -1;
     c->cur_fb = c->cur;
-    c->fbs[c->cur_fb].is_clear = true;
+    {
+        Framebuffer& F = c->fbs[c->cur_fb];
+        F.is_clear = true; F.all_in_memory = false;
+        if (++F.epoch == 0u) {                              // the 32-bit epoch wraps: forget every old tile word (the lane that used the image last has long finished)
+            HIPCHK(c, fb_access(c, F) == GS4D_OK ? hipMemsetAsync(F.tstate, 0, (size_t)c->tiles_x * c->tiles_y * 4, lane(c).s) : hipErrorUnknown);
+            F.epoch = 1;
+        }
+    }
     memcpy(c->fbs[c->cur_fb].clear, c->clear, 16);
     // Whatever a still-unvalidated draw left in the image that is being cleared is discarded with it — the draw is never re-run — but its
     // verdict is still read (resolve_lane, at the latest when its lane draws again): what it found out about the scene's lists feeds the next
@@ -1018,7 +1036,6 @@ static int draw_common(gs4d_ctx* c, DrawArgs& a) {
     rc = resolve_image(c, c->cur_fb); if (rc) return rc;
     Lane& L = lane(c);
     a.lane = c->cur; a.fb = c->cur_fb;
-    a.fb_was_clear = c->fbs[c->cur_fb].is_clear;
     memcpy(a.clear, c->fbs[c->cur_fb].clear, 16);
     a.shard_rank = c->shard_rank; a.shard_world = c->shard_world;
     // Which path: the unordered one whenever the blend order is known without reading a sort index — instance k draws record k, or the
@@ -1171,9 +1188,11 @@ static int read_device_common(gs4d_ctx* c, int frames_back, void* dptr, bool rgb
         HIPCHK(c, hipStreamWaitEvent(L.s, c->ev_user, 0));
     }
     if (li == c->cur) { rc = fb_access(c, F); if (rc) return rc; }
-    if (F.is_clear) { HIPCHK(c, launch_fill(L.s, F.mem, (size_t)c->W * c->H, F.clear)); F.is_clear = false; }
-    if (rgba8) HIPCHK(c, launch_pack_rgba8(L.s, F.mem, (size_t)c->W * c->H, (uint32_t*)dptr));
-    else HIPCHK(c, hipMemcpyAsync(dptr, F.mem, (size_t)c->W * c->H * 16, hipMemcpyDeviceToDevice, L.s));
+    if (rgba8) HIPCHK(c, launch_pack_rgba8(L.s, F.mem, F.tstate, F.epoch, F.clear, c->W, c->H, c->tiles_x, (uint32_t*)dptr));      // lazily clear tiles are packed as the clear colour
+    else {
+        if (!F.all_in_memory) { HIPCHK(c, launch_fill_unwritten(L.s, F.mem, F.tstate, F.epoch, c->tiles_x, c->tiles_y, c->W, c->H, F.clear)); F.all_in_memory = true; F.is_clear = false; }
+        HIPCHK(c, hipMemcpyAsync(dptr, F.mem, (size_t)c->W * c->H * 16, hipMemcpyDeviceToDevice, L.s));
+    }
     if (li != c->cur) HIPCHK(c, hipEventRecord(L.ev_tail, L.s));      // the lane's tail event keeps covering everything queued on it
     if (c->user) {                                          // work the caller queues on its stream after this call sees the pixels
         HIPCHK(c, hipEventRecord(c->ev_readback, L.s));
@@ -1241,11 +1260,10 @@ int gs4d_read_band_rgba8_device(gs4d_ctx* c, void* dptr, size_t bytes) {
     if (bytes != (size_t)rows * c->W * 4) return fail(c, GS4D_E_INVALID, "read_band_rgba8_device: bytes != band_rows*width*4");
     int rc = resolve_image(c, c->cur_fb); if (rc) return rc;
     rc = after_user_stream(c); if (rc) return rc;
-    rc = materialise_fb(c); if (rc) return rc;
     Framebuffer& F = c->fbs[c->cur_fb];
     rc = fb_access(c, F); if (rc) return rc;
     Lane& L = lane(c);
-    HIPCHK(c, launch_pack_rgba8_band(L.s, F.mem, c->W, c->H, c->shard_rank, c->shard_world, rows, (uint32_t*)dptr));
+    HIPCHK(c, launch_pack_rgba8_band(L.s, F.mem, F.tstate, F.epoch, F.clear, c->W, c->H, c->tiles_x, c->shard_rank, c->shard_world, rows, (uint32_t*)dptr));
     if (c->user) {
         HIPCHK(c, hipEventRecord(c->ev_readback, L.s));
         HIPCHK(c, hipStreamWaitEvent(c->user, c->ev_readback, 0));

@@ -145,7 +145,7 @@ hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uin
 hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint32_t* trects, const float4* proj, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint);
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
-                               int premult_c, int fb_is_clear, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs);
+                               int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs);
 
 #ifdef __HIPCC__
 // tiles touched by a pixel rectangle (x0|y0<<16, x1|y1<<16; x0 > x1: none), restricted to the tile rows ty % world == rank
@@ -221,12 +221,13 @@ hipError_t launch_binning(hipStream_t st, BinScratch& b, const uint32_t* trects,
 hipError_t launch_tile_ranges(hipStream_t st, BinScratch& b, const uint32_t* pair_keys, size_t pair_cap, size_t ntiles);
 
 // ---- composite.hip ----
+// tstate / epoch: the image's tile state (composite.hip): tstate[tile] == epoch <=> the tile's pixels are in memory, else it is still the clear colour
 hipError_t launch_composite(hipStream_t st, const float4* proj, const uint32_t* pair_vals, uint32_t* ranges, const uint32_t* total, int tiles_x, int tiles_y,
-                            int W, int H, int premult_c, int fb_is_clear, const float clear[4], float4* fb, int blend_src, int blend_dst);
-hipError_t launch_fill(hipStream_t st, float4* fb, size_t npix, const float clear[4]);
-hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, size_t npix, uint32_t* out);
+                            int W, int H, int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, int blend_src, int blend_dst);
+hipError_t launch_fill_unwritten(hipStream_t st, float4* fb, uint32_t* tstate, uint32_t epoch, int tiles_x, int tiles_y, int W, int H, const float clear[4]);
+hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, const uint32_t* tstate, uint32_t epoch, const float clear[4], int W, int H, int tiles_x, uint32_t* out);
 // the pixel rows of the tile rows ty % world == rank, top of the band = the context's first tile row; band_rows pixel rows in all
-hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, int W, int H, int rank, int world, int band_rows, uint32_t* out);
+hipError_t launch_pack_rgba8_band(hipStream_t st, const float4* fb, const uint32_t* tstate, uint32_t epoch, const float clear[4], int W, int H, int tiles_x, int rank, int world, int band_rows, uint32_t* out);
 
 // ---- lines.hip ----
 struct LineParams { float vp[16]; float rgba[4]; int W, H; int blend_src, blend_dst; };
