@@ -34,7 +34,7 @@ struct Buffer {
     size_t bytes = 0;
     uint64_t version = 0;          // bumped by every write; the SoA shadow and the keygen-histogram hand-off compare against it
     float4* soa = nullptr;         // lazily built SoA shadow of 96-B SplatData records
-    bool soa_compact = false;      // ... in the 72-byte layout of a symmetric sig (preprocess.hip)
+    SoaInfo soa_info;              // ... its layout (preprocess.hip): 64 B/record for static 3D splats, 72 for a symmetric sig, 96 otherwise
     size_t soa_n = 0;
     uint64_t soa_version = ~0ull;
     uint32_t* bbox_dev = nullptr;  // 16 words: bounding box of pos / mu_t / velocity, reduced by the repack kernel
@@ -158,7 +158,7 @@ struct gs4d_ctx {
              int key_mode = 0; uint32_t bias = 0, span = 0xFFFFFFFFu; float view[16] = { 0 }; } po;
     int blend_src = GS4D_SRC_ALPHA, blend_dst = GS4D_ONE_MINUS_SRC_ALPHA;     // glBlendFunc state (Application.cpp:137-138, 150)
     bool defer_order = true;           // GS4D_FUSE_KEYGEN=0 switches the deferral off (test hook)
-    uint64_t stat_fused = 0, stat_renamed = 0;
+    uint64_t stat_fused = 0, stat_renamed = 0, stat_shadow_bytes = 0;
     bool rename_storage = true;        // GS4D_RENAME=0 switches the storage exchange off (test hook)
     int shrink_votes = 0;
     // Two ways to get a tile's list into blend order.  Lists of up to V2_MAX_LIST entries: built unordered, ordered by the wave that
@@ -294,15 +294,21 @@ int ensure_soa(gs4d_ctx* c, Buffer& b) {
     uint32_t init[16]; for (int i = 0; i < 16; ++i) init[i] = i < 7 ? 0xFFFFFFFFu : 0u;
     if (!b.bbox_dev) HIPCHK(c, hipMalloc(&b.bbox_dev, 64));
     uint32_t got[16];
-    // the compact layout first (every sig the reference builds is symmetric); a record that is not sends the repack round again
+    // the most compact layout the records allow: static 3D splats (the time row / column of sig and mu_t the same in every record: those of
+    // record 0), else a symmetric sig, else everything.  The kernel verifies the assumption for every record; a violation sends the round again.
     const bool allow_compact = !(getenv("GS4D_SOA_FULL") && atoi(getenv("GS4D_SOA_FULL")));             // test hook: always the 96-byte layout (upload-time code: read per repack)
-    for (int attempt = allow_compact ? 0 : 1; attempt < 2; ++attempt) {
-        b.soa_compact = attempt == 0;
+    float rec0[24] = { 0 };
+    if (n) { HIPCHK(c, hipMemcpyAsync(rec0, b.d, 96, hipMemcpyDeviceToHost, L.s)); HIPCHK(c, hipStreamSynchronize(L.s)); }
+    static const int order[3] = { SOA_STATIC3D, SOA_SYM, SOA_FULL };
+    for (int attempt = allow_compact ? 0 : 2; attempt < 3; ++attempt) {
+        b.soa_info = SoaInfo();
+        b.soa_info.layout = order[attempt];
+        if (order[attempt] == SOA_STATIC3D) { const float cs[8] = { rec0[3], rec0[11], rec0[15], rec0[19], rec0[20], rec0[21], rec0[22], rec0[23] }; memcpy(b.soa_info.consts, cs, sizeof cs); }
         HIPCHK(c, hipMemcpyAsync(b.bbox_dev, init, 64, hipMemcpyHostToDevice, L.s));
-        HIPCHK(c, launch_soa_repack(L.s, (const float*)b.d, n, b.soa, b.bbox_dev, b.soa_compact));
+        HIPCHK(c, launch_soa_repack(L.s, (const float*)b.d, n, b.soa, b.bbox_dev, b.soa_info));
         HIPCHK(c, hipMemcpyAsync(got, b.bbox_dev, 64, hipMemcpyDeviceToHost, L.s));
         HIPCHK(c, hipStreamSynchronize(L.s));      // the shadow is complete before any lane can be asked to read it
-        if (!b.soa_compact || got[15] == 0) break;
+        if (order[attempt] == SOA_FULL || got[15] == 0) break;
     }
     auto ord2f = [](uint32_t u) { u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; memcpy(&f, &u, 4); return (double)f; };
     b.bb_ok = n > 0 && got[14] == 0;
@@ -457,7 +463,10 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
-            else HIPCHK(c, launch_preprocess_4d(L.s, data->soa, data->soa_n, data->soa_compact, npre, a.u, c->W, c->H, po, tc));
+            else {
+                HIPCHK(c, launch_preprocess_4d(L.s, data->soa, data->soa_n, data->soa_info, npre, a.u, c->W, c->H, po, tc));
+                c->stat_shadow_bytes = data->soa_info.layout == SOA_STATIC3D ? 64 : data->soa_info.layout == SOA_SYM ? 72 : 96;
+            }
         }
         L.proj_n = npre;
         if (regen) {
@@ -475,7 +484,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             if (!kh) return hipfail(c, he, "sort_hist_slot");
             const float cam[3] = { a.ks.camx, a.ks.camy, a.ks.camz };
             float view[16] = { 0 }; view[2] = a.ks.vr0; view[6] = a.ks.vr1; view[10] = a.ks.vr2; view[14] = a.ks.vr3;
-            HIPCHK(c, launch_keygen(L.s, data->soa, soa_sig3(data->soa, data->soa_n, data->soa_compact), npre, a.ks.t, cam, view, a.ks.mode == KEYSRC_VIEWZ ? GS4D_KEY_VIEW_Z : GS4D_KEY_REF_INV_EUCLID,
+            HIPCHK(c, launch_keygen(L.s, data->soa, soa_sig3(data->soa, data->soa_n, data->soa_info), data->soa_info, npre, a.ks.t, cam, view, a.ks.mode == KEYSRC_VIEWZ ? GS4D_KEY_VIEW_Z : GS4D_KEY_REF_INV_EUCLID,
                                     (float*)L.regen_keys, L.order_copy, kh, a.ks.bias, 0xFFFFFFFFu, L.host_total_dev + 4));
             L.depth_sort.hist_bias = a.ks.bias;
             HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, L.regen_keys, L.order_copy, npre, nullptr, a.keybits, true));
@@ -597,7 +606,7 @@ int flush_order(gs4d_ctx* c) {
         uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, po.n, &he);
         if (!kh) return hipfail(c, he, "sort_hist_slot");
         StageTimer tm(c, GS4D_T_KEYGEN);
-        HIPCHK(c, launch_keygen(L.s, D->soa, soa_sig3(D->soa, D->soa_n, D->soa_compact), po.n, po.t, po.cam, po.view, po.key_mode, (float*)K->d, (uint32_t*)I->d, kh, po.bias, po.span, L.host_total_dev + 4));
+        HIPCHK(c, launch_keygen(L.s, D->soa, soa_sig3(D->soa, D->soa_n, D->soa_info), D->soa_info, po.n, po.t, po.cam, po.view, po.key_mode, (float*)K->d, (uint32_t*)I->d, kh, po.bias, po.span, L.host_total_dev + 4));
         L.depth_sort.hist_bias = po.bias;
     }
     if (po.sorted) {
@@ -1347,7 +1356,7 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     if (!c || !stats) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y;
+    stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y | (c->stat_shadow_bytes << 32);
     stats[4] = c->stat_depth_passes; stats[5] = (c->stat_tile_passes & 0xFFFFFFFFull) | (c->stat_renamed << 32); stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }

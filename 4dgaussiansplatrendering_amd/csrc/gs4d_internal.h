@@ -49,7 +49,17 @@ void sort_scratch_free(SortScratch& s);
 hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals = false);
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
 hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
-hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
+// Layout of the SoA shadow (preprocess.hip).  The repack kernel verifies what a compact layout assumes, bit for bit, for every record, and
+// reports a violation in bbox[15]; the caller then repacks in the next layout down.
+//   SOA_STATIC3D  64 B/record: a static 3D splat in the reference's 4D record — mu_t, the time row and the time column of sig are the same
+//                 eight values in every record (SoaInfo::consts; Scenes.h ObjectDisplay / a 3D covariance with Sigma44 = 1) — keeps position,
+//                 colour and the nine spatial elements of sig: planes (px py pz s00), col, (s01 s02 s10 s11), (s12 s20 s21 s22)
+//   SOA_SYM       72 B/record: a symmetric sig without its mirrored half
+//   SOA_FULL      96 B/record: pos, col, sig[0..3]
+enum { SOA_FULL = 0, SOA_SYM = 1, SOA_STATIC3D = 2 };
+struct SoaInfo { int layout = SOA_FULL; float consts[8] = { 0 }; };      // consts: pos.w, sig[0][3], sig[1][3], sig[2][3], sig[3][0..3] of a static set
+// sig3 == nullptr: a static set (SOA_STATIC3D) — mu_t and sig[3] are info.consts for every record
+hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, const SoaInfo& info, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
                          uint32_t bias, uint32_t span, uint32_t* err);
 
 // ---- digit histograms for the radix sort, accumulated by whichever kernel produces the keys ----
@@ -193,13 +203,12 @@ template <class F> __device__ __forceinline__ void for_each_tile(const TRect& r,
 #endif
 
 // ---- preprocess.hip ----
-// compact: the 72-byte layout of a symmetric sig (preprocess.hip); bbox[15] comes back non-zero if some record's sig is NOT symmetric bit for bit
-// (the caller then repacks in the full layout).  Either way plane 0 is pos and soa_sig3() is the plane of sig[3] (what key generation reads).
-hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* n * 96 bytes */, uint32_t* bbox /* [16], preset: min = ~0, max = 0 */, bool compact);
-inline const float4* soa_sig3(const float4* soa, size_t n, bool compact) { return soa + (compact ? 3 : 5) * n; }
+hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa /* n * 96 bytes */, uint32_t* bbox /* [16], preset: min = ~0, max = 0 */, const SoaInfo& info);
+// plane 0 holds pos.xyz in every layout; the plane of sig[3] (what key generation reads beside it), or null when it is one of the constants
+inline const float4* soa_sig3(const float4* soa, size_t n, const SoaInfo& info) { return info.layout == SOA_STATIC3D ? nullptr : soa + (info.layout == SOA_SYM ? 3 : 5) * n; }
 // Each preprocess launch also writes the packed tile rectangle of every record (pack_trect).
 struct PreOut { float4* proj; uint32_t* trects; };
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n /* records in the buffer: the plane stride */, bool compact, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n /* records in the buffer: the plane stride */, const SoaInfo& info, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& u, int W, int H, PreOut out, const TileCount& tc);
 

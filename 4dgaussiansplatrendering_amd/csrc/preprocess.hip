@@ -13,19 +13,24 @@
 
 namespace gs4d {
 
-// AoS 96-B SplatData (Scenes.h:22-37) -> planes.  Two layouts (SoaLayout, gs4d_internal.h):
-//   full     6 planes of float4: pos, col, sig[0], sig[1], sig[2], sig[3]                                                 96 B / record
-//   compact  pos, col, U = (s00, s01, s02, s11), V = sig[3] = (s03, s13, s23, s33) as float4 planes, W = (s12, s22) as a float2 plane   72 B / record
-// The compact one holds a SYMMETRIC sig without its mirrored half — every covariance the reference builds is one (Splat.h:127, 141-154) —
-// bit for bit: the repack kernel compares sig[c][r] with sig[r][c] as bit patterns for every record and raises bbox[15] if any pair
-// differs; the host then repacks in the full layout.  A quarter of the projection's read traffic is gone for the records the reference makes.
+// AoS 96-B SplatData (Scenes.h:22-37) -> planes.  Three layouts (SOA_*, gs4d_internal.h):
+//   full      6 planes of float4: pos, col, sig[0], sig[1], sig[2], sig[3]                                                96 B / record
+//   sym       pos, col, U = (s00, s01, s02, s11), V = sig[3] = (s03, s13, s23, s33) as float4 planes, W = (s12, s22) as a float2 plane   72 B / record
+//   static3d  (px py pz s00), col, (s01 s02 s10 s11), (s12 s20 s21 s22): the 16 values of a STATIC 3D splat that differ from record to record   64 B / record
+// sym holds a SYMMETRIC sig without its mirrored half — every covariance the reference's 4D scenes build is one (Splat.h:127, 141-154).
+// static3d is for a set of 3D splats kept in the reference's 4D record: mu_t, sig's time column sig[c][3] and its time row sig[3][*] are
+// the same eight values in every record (0, 0, 0, 0, (0, 0, 0, 1) for a 3D covariance: Scenes.h ObjectDisplay, the cube configs) and travel
+// as kernel arguments.  Both are exact: the repack kernel compares what the layout assumes as bit patterns for every record and raises
+// bbox[15] if any record breaks it; the host then repacks in the next layout down.  A third (a quarter) of the projection's read traffic is gone.
 // float <-> unsigned with the same order, for atomicMin/atomicMax on floats
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 
 // Also reduces the bounding box of what the sort key depends on — position, mu_t and the velocity column sig[3].xyz
 // (Scenes.h:28-36) — into bbox[0..6] = min, bbox[7..13] = max (order-preserving uint form), bbox[14] = non-finite input seen.
-template <bool COMPACT>
-__global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ soa, uint32_t* __restrict__ bbox) {
+struct SoaConsts { float v[8]; };
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ aos, uint32_t n, float4* __restrict__ soa, uint32_t* __restrict__ bbox, SoaConsts cs) {
+    constexpr bool COMPACT = LAYOUT != SOA_FULL;
     // one wave moves 64 records = 384 float4, read fully coalesced, written as 6 x 64 contiguous float4
     __shared__ float4 stage[4][384];
     __shared__ uint32_t red[4][16];
@@ -46,14 +51,21 @@ __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ a
         }
         __builtin_amdgcn_wave_barrier();               // stage[w] is private to the wave
         if (lane < nrec) {
-            if (COMPACT) {
+            auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b); };
+            if (LAYOUT == SOA_STATIC3D) {
+                const float4 ps = stage[w][lane * 6u + 0], c0 = stage[w][lane * 6u + 2], c1 = stage[w][lane * 6u + 3], c2 = stage[w][lane * 6u + 4], c3 = stage[w][lane * 6u + 5];
+                soa[rec0 + lane] = make_float4(ps.x, ps.y, ps.z, c0.x);
+                soa[(size_t)n + rec0 + lane] = stage[w][lane * 6u + 1];
+                soa[(size_t)2 * n + rec0 + lane] = make_float4(c0.y, c0.z, c1.x, c1.y);
+                soa[(size_t)3 * n + rec0 + lane] = make_float4(c1.z, c2.x, c2.y, c2.z);
+                if (!(same(ps.w, cs.v[0]) && same(c0.w, cs.v[1]) && same(c1.w, cs.v[2]) && same(c2.w, cs.v[3]) && same(c3.x, cs.v[4]) && same(c3.y, cs.v[5]) && same(c3.z, cs.v[6]) && same(c3.w, cs.v[7]))) asym = true;
+            } else if (LAYOUT == SOA_SYM) {
                 const float4 c0 = stage[w][lane * 6u + 2], c1 = stage[w][lane * 6u + 3], c2 = stage[w][lane * 6u + 4], c3 = stage[w][lane * 6u + 5];
                 soa[rec0 + lane] = stage[w][lane * 6u + 0];
                 soa[(size_t)n + rec0 + lane] = stage[w][lane * 6u + 1];
                 soa[(size_t)2 * n + rec0 + lane] = make_float4(c0.x, c0.y, c0.z, c1.y);
                 soa[(size_t)3 * n + rec0 + lane] = c3;
                 reinterpret_cast<float2*>(soa + (size_t)4 * n)[rec0 + lane] = make_float2(c1.z, c2.z);
-                auto same = [](float a, float b) { return __float_as_uint(a) == __float_as_uint(b); };
                 // sig[c][r] == sig[r][c]: c0.y = sig[0][1] vs c1.x = sig[1][0], ...
                 if (!(same(c0.y, c1.x) && same(c0.z, c2.x) && same(c0.w, c3.x) && same(c1.z, c2.y) && same(c1.w, c3.y) && same(c2.w, c3.z))) asym = true;
             } else {
@@ -91,11 +103,13 @@ __global__ __launch_bounds__(256) void k_soa_repack(const float4* __restrict__ a
     }
 }
 
-hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa, uint32_t* bbox, bool compact) {
+hipError_t launch_soa_repack(hipStream_t st, const float* aos96, size_t n, float4* soa, uint32_t* bbox, const SoaInfo& info) {
     if (n == 0) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 2048);
-    if (compact) k_soa_repack<true><<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox);
-    else k_soa_repack<false><<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox);
+    SoaConsts cs; for (int k = 0; k < 8; ++k) cs.v[k] = info.consts[k];
+    if (info.layout == SOA_STATIC3D) k_soa_repack<SOA_STATIC3D><<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox, cs);
+    else if (info.layout == SOA_SYM) k_soa_repack<SOA_SYM><<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox, cs);
+    else k_soa_repack<SOA_FULL><<<dim3(blocks), dim3(256), 0, st>>>((const float4*)aos96, (uint32_t)n, soa, bbox, cs);
     return hipGetLastError();
 }
 
@@ -267,6 +281,7 @@ __device__ __forceinline__ bool project3d(const PU& u, float mx, float my, float
 // One record each: returns its pixel rectangle, and through `key` its blend-order key (unordered path).
 struct Src4D { const float4* soa; uint32_t stride; };      // six planes of `stride` float4 (the buffer's record count, not the draw's)
 struct Src4DSym { const float4* soa; uint32_t stride; };   // the compact layout of a symmetric sig: pos, col, U, V as float4 planes, W as a float2 plane
+struct Src4DStatic { const float4* soa; uint32_t stride; SoaConsts cs; };      // static 3D splats: four float4 planes, the time row / column of sig and mu_t as constants
 struct Src3D { const float* verts; };
 struct Src2D { const float* recs; };
 
@@ -286,6 +301,14 @@ __device__ __forceinline__ uint2 project_record(const Src4DSym& src, uint32_t n,
     const float2 W = reinterpret_cast<const float2*>(soa + 4 * ps)[i];
     // sig[c] = column c; the mirrored elements are the same bits (verified by the repack kernel)
     return project_4d(pos, col, make_float4(U.x, U.y, U.z, V.x), make_float4(U.y, U.w, W.x, V.y), make_float4(U.z, W.x, W.y, V.z), V, i, u, out, ks, key);
+}
+__device__ __forceinline__ uint2 project_record(const Src4DStatic& src, uint32_t n, uint32_t i, const PU& u, const PreOut& out, const KeySrc& ks, uint32_t& key) {
+    const float4* __restrict__ soa = src.soa;
+    const size_t ps = src.stride;
+    const float4 A = soa[i], col = soa[ps + i], B = soa[2 * ps + i], C = soa[3 * ps + i];
+    const float* c = src.cs.v;
+    return project_4d(make_float4(A.x, A.y, A.z, c[0]), col, make_float4(A.w, B.x, B.y, c[1]), make_float4(B.z, B.w, C.x, c[2]), make_float4(C.y, C.z, C.w, c[3]), make_float4(c[4], c[5], c[6], c[7]),
+                      i, u, out, ks, key);
 }
 __device__ __forceinline__ uint2 project_4d(const float4& pos, const float4& col, const float4& s0, const float4& s1, const float4& s2, const float4& s3,
                                             uint32_t i, const PU& u, const PreOut& out, const KeySrc& ks, uint32_t& key) {
@@ -414,8 +437,9 @@ static hipError_t launch_pre(hipStream_t st, SRC src, size_t n, const Uniforms& 
     else k_preprocess<SRC><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n, bool compact, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
-    return compact ? launch_pre(st, Src4DSym{ soa, (uint32_t)soa_n }, n, un, W, H, out, tc) : launch_pre(st, Src4D{ soa, (uint32_t)soa_n }, n, un, W, H, out, tc);
+hipError_t launch_preprocess_4d(hipStream_t st, const float4* soa, size_t soa_n, const SoaInfo& info, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
+    if (info.layout == SOA_STATIC3D) { Src4DStatic s{ soa, (uint32_t)soa_n, SoaConsts() }; for (int k = 0; k < 8; ++k) s.cs.v[k] = info.consts[k]; return launch_pre(st, s, n, un, W, H, out, tc); }
+    return info.layout == SOA_SYM ? launch_pre(st, Src4DSym{ soa, (uint32_t)soa_n }, n, un, W, H, out, tc) : launch_pre(st, Src4D{ soa, (uint32_t)soa_n }, n, un, W, H, out, tc);
 }
 hipError_t launch_preprocess_3d(hipStream_t st, const float* verts72, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src3D{ verts72 }, n, un, W, H, out, tc); }
 hipError_t launch_preprocess_2d(hipStream_t st, const float* rec48, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) { return launch_pre(st, Src2D{ rec48 }, n, un, W, H, out, tc); }

@@ -26,7 +26,8 @@ namespace gs4d {
 __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, const float4* __restrict__ sig3, uint32_t n, float t,
                                                 float camx, float camy, float camz, float4 vrow2 /* view row 2: V[2],V[6],V[10],V[14] */, int key_mode,
                                                 float* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ ghist /* digit histograms of (key - bias), for the sort */,
-                                                uint32_t bias /* host-proven lower bound of every key's bit pattern */, uint32_t span /* ... and of (key - bias) from above */, uint32_t* __restrict__ err) {
+                                                uint32_t bias /* host-proven lower bound of every key's bit pattern */, uint32_t span /* ... and of (key - bias) from above */, uint32_t* __restrict__ err,
+                                                float4 csig3, float cmut /* sig3 == nullptr (a static set: SOA_STATIC3D): sig[3] and mu_t of every record */) {
     __shared__ uint32_t h[OS_MAX_PASSES][256];
     os_hist_clear(h, threadIdx.x);
     __syncthreads();
@@ -35,8 +36,9 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, 
         const bool in = i < n;
         float key = 0.0f;
         if (in) {
-            const float4 p = pos[i];
-            const float4 s = sig3[i];
+            float4 p = pos[i];
+            float4 s = csig3;
+            if (sig3) s = sig3[i]; else p.w = cmut;        // uniform
             if (key_mode == GS4D_KEY_REF_INV_EUCLID) {
                 float ct = t - p.w;                        // Scenes.h:30
                 float x = p.x + s.x * ct;                  // :31-33  (sig[3].xyz, NOT divided by Sigma44)
@@ -62,12 +64,13 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, 
     os_hist_flush(h, ghist, OS_MAX_PASSES, threadIdx.x);
 }
 
-hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
+hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, const SoaInfo& info, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
                          uint32_t bias, uint32_t span, uint32_t* err) {
     if (n == 0) return hipSuccess;
     float4 vr = make_float4(view[2], view[6], view[10], view[14]);
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);     // grid-stride: bounds the histogram flush to 1024 workgroups
-    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist, bias, span, err);
+    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist, bias, span, err,
+                                                     make_float4(info.consts[4], info.consts[5], info.consts[6], info.consts[7]), info.consts[0]);
     return hipGetLastError();
 }
 

@@ -271,6 +271,52 @@ def test_compact_and_full_record_shadows(gs4d, oracle, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_static_3d_record_shadow(gs4d, oracle, monkeypatch, fuse):
+    """A set of static 3D splats in the reference's 4D record (Scenes.h ObjectDisplay: mu_t = 0, no space-time covariance, Sigma44 = 1 — the
+    benchmark's records) has eight values that are the same in every record; the private shadow then keeps 64 bytes a record and passes
+    the eight as constants.  Same projected records, same keys and same image as the 96-byte layout, bit for bit; any record that differs
+    in one of the eight (even by a sign bit) sends the buffer to the next layout down and the result is still the reference's."""
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    monkeypatch.setenv("GS4D_FUSE_KEYGEN", str(fuse))             # 0: the stand-alone key kernel reads the shadow too
+    from test_gpu_render import gpu_frame, check_projected
+    n, W, H = 20000, 640, 360
+    pos, q, sc, rgba = scenes.cube_params(n, seed=5)
+    rec = gs4d.build_records_3d(pos, q, sc * 3.0, rgba)
+    assert np.all(rec[:, 3] == 0) and np.all(rec[:, 20:23] == 0) and np.all(rec[:, 23] == 1)
+    cam = scenes.CAM_CUBE
+    t = 3.0
+    out = {}
+    for full in (0, 1):
+        monkeypatch.setenv("GS4D_SOA_FULL", str(full))
+        ctx = gs4d.Context(W, H)
+        img, projd, st, (view, proj) = gpu_frame(ctx, gs4d, rec, cam, t=t)
+        assert st["record_read_bytes"] == (96 if full else 64)
+        ctx.close()
+        out[full] = (img, projd)
+    monkeypatch.delenv("GS4D_SOA_FULL", raising=False)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    check_projected(oracle, out[0][1], oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, 0.0))
+    eimg, _, _ = oracle.render_4d(rec, True, t, 0.0, cam[0], view, proj, W, H)
+    assert linf(out[0][0], eimg) <= TOL
+    # a symmetric set whose time components are NOT constant: 72 bytes; one record with mu_t = -0.0 (another bit pattern than 0.0): not 64;
+    # an asymmetric spatial block alone does not matter to the static layout (it keeps all nine elements): still 64
+    for edit, want in ((lambda r: r.__setitem__((slice(None, None, 9), 3), 0.5), 72), (lambda r: r.__setitem__((n // 2, 3), -0.0), 72),
+                       (lambda r: r.__setitem__((7, 8 + 1), r[7, 8 + 1] * 1.5 + 0.01), 64), (lambda r: r.__setitem__((0, 23), 2.0), 72)):
+        rec2 = rec.copy()
+        sig = rec2[:, 8:].reshape(-1, 4, 4)
+        iu = np.triu_indices(4, 1)
+        sig[:, iu[1], iu[0]] = sig[:, iu[0], iu[1]]
+        edit(rec2)
+        ctx = gs4d.Context(W, H)
+        img2, projd2, st2, _ = gpu_frame(ctx, gs4d, rec2, cam, t=t)
+        assert st2["record_read_bytes"] == want, want
+        ctx.close()
+        check_projected(oracle, projd2, oracle.preprocess(oracle.MODE_4D, rec2, view, proj, W, H, t, 0.0))
+        eimg2, _, _ = oracle.render_4d(rec2, True, t, 0.0, cam[0], view, proj, W, H)
+        assert linf(img2, eimg2) <= TOL
+
+
 @pytest.mark.parametrize("rename", [1, 0])
 def test_one_key_pair_for_all_frames(gs4d, oracle, monkeypatch, rename):
     """The reference's buffer layout — ONE key buffer and ONE index buffer for every frame (Scenes.h m_key_buf / m_values_buf) — with frames
