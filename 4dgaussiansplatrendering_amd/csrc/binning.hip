@@ -48,14 +48,14 @@ struct Rect { uint32_t tx0, ty0, tx1, ty1, count, tstep; };     // tile rows ty0
 
 // writes the entries of one splat and counts their tile-id digits for the radix sort that follows (no separate histogram launch)
 __device__ __forceinline__ void emit_tiles(const Rect& r, uint32_t off, uint32_t rec, uint32_t tiles_x, uint32_t first, uint32_t stride,
-                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t (*h)[256], int passes) {
+                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t (*h)[OS_MAX_BINS], int passes, int rb) {
     const uint32_t wx = r.tx1 - r.tx0 + 1u;
     for (uint32_t j = first; j < r.count; j += stride) {
         const uint32_t ty = r.ty0 + (j / wx) * r.tstep, tx = r.tx0 + j % wx;
         const uint32_t id = ty * tiles_x + tx;
         pk[off + j] = id;
         pv[off + j] = rec;
-        if (h) for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(id >> (8 * p)) & 255u], 1u);
+        if (h) for (int p = 0; p < passes; ++p) atomicAdd(&h[p][(id >> (rb * p)) & ((1u << rb) - 1u)], 1u);
     }
 }
 
@@ -75,7 +75,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __restrict__ trects, int trects_in_order, const float4* __restrict__ proj, const uint32_t* __restrict__ order, uint32_t* __restrict__ order_copy, uint32_t ninst, uint32_t nrecords,
                                                           unsigned long long* status, unsigned long long* gstatus, uint32_t* __restrict__ total, uint32_t cap, uint32_t tiles_x,
                                                           uint32_t* __restrict__ pk, uint32_t* __restrict__ pv, uint32_t* err,
-                                                          uint32_t* __restrict__ ghist, int passes, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base, int dbg_arg,
+                                                          uint32_t* __restrict__ ghist, int passes_rb /* passes | digit bits << 8 of the tile sort that follows */, uint32_t* __restrict__ total_host, uint32_t epoch, uint32_t* ticket, uint32_t ticket_base, int dbg_arg,
                                                           uint32_t shard_rank, uint32_t shard_world /* tile row ty is ours iff ty % shard_world == shard_rank */) {
 #ifdef GS4D_TUNING
     const int dbg = dbg_arg;             // ablation bits (GS4D_EMIT_DBG): tuning builds only (make TUNING=1)
@@ -85,7 +85,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
     __shared__ uint32_t wsum[BIN_WAVES];
     __shared__ unsigned long long s_prefix;
     __shared__ uint32_t s_blk;
-    __shared__ uint32_t h[OS_MAX_PASSES][256];
+    __shared__ uint32_t h[OS_MAX_PASSES][OS_MAX_BINS];
+    const int passes = passes_rb & 255, rb = passes_rb >> 8;
     if (threadIdx.x < 256u) os_hist_clear(h, threadIdx.x);
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // the slice of instances is handed out by ticket (start order), so the look-back only ever waits for running workgroups
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
         const bool fits = o64 + r[j].count <= (unsigned long long)cap;      // entries beyond the capacity are not written; the draw is re-run
         const uint32_t o = (uint32_t)o64;
         const bool big = fits && r[j].count > 32u;
-        if (fits && !big && !(dbg & 4)) emit_tiles(r[j], o, rec[j], tiles_x, 0u, 1u, pk, pv, (dbg & 2) ? nullptr : h, passes);
+        if (fits && !big && !(dbg & 4)) emit_tiles(r[j], o, rec[j], tiles_x, 0u, 1u, pk, pv, (dbg & 2) ? nullptr : h, passes, rb);
         // large footprints: the whole wave writes one splat's entries
         uint64_t m = __ballot(big);
         while (m) {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_bin_emit(const uint32_t* __rest
             rr.tx0 = __shfl(r[j].tx0, src, 64); rr.ty0 = __shfl(r[j].ty0, src, 64); rr.tx1 = __shfl(r[j].tx1, src, 64); rr.ty1 = __shfl(r[j].ty1, src, 64);
             rr.count = __shfl(r[j].count, src, 64); rr.tstep = __shfl(r[j].tstep, src, 64);
             const uint32_t o2 = __shfl(o, src, 64), rec2 = __shfl(rec[j], src, 64);
-            emit_tiles(rr, o2, rec2, tiles_x, lane, 64u, pk, pv, h, passes);
+            emit_tiles(rr, o2, rec2, tiles_x, lane, 64u, pk, pv, h, passes, rb);
         }
     }
     __syncthreads();

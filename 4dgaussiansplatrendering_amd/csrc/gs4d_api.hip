@@ -341,14 +341,15 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, cons
     const int blend_src = a.blend_src, blend_dst = a.blend_dst;
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
-    const int tile_passes = (tile_bits + 7) / 8 < 2 ? 2 : (tile_bits + 7) / 8;
+    // (4K: 129 600 tiles = 17 bits — three passes of 8-bit digits, two of 9-bit ones)
+    const int tile_rb = L.pair_sort.hist_rb = sort_plan_rb(L.pair_sort, L.pair_cap, tile_bits, false), tile_passes = sort_plan_passes(tile_bits, tile_rb);
     {
         StageTimer t(c, GS4D_T_BINNING);
         hipError_t he = hipSuccess;
         uint32_t* ph = sort_hist_slot(L.s, L.pair_sort, L.pair_cap, &he);      // the emit kernel also counts the tile-id digits
         if (!ph) return hipfail(c, he, "sort_hist_slot");
         HIPCHK(c, launch_binning(L.s, L.bin, L.trects, L.trects_in_order, L.proj, order, order_copy, ninst, nrecords, c->tiles_x, c->tiles_y, L.pair_keys, L.pair_vals, L.pair_cap, L.host_total_dev + 4,
-                                 ph, tile_passes, L.host_total_dev, a.shard_rank, a.shard_world));
+                                 ph, tile_passes | (tile_rb << 8), L.host_total_dev, a.shard_rank, a.shard_world));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));     // the last binning workgroup wrote the total straight into pinned host memory
     {
@@ -392,7 +393,11 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
 }
 
 // `preprocess` false: the re-run of a draw whose tile lists overflowed (projected records and the sort-index copy are still valid).
+// width of a key span in bits (what the depth sort and the compositor's list sort have to look at)
+static int span_bits(uint32_t span) { return span == 0xFFFFFFFFu ? 32 : std::max(1, 32 - __builtin_clz(span | 1u)); }
+
 int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
+    const int fuse_bits = span_bits(a.fuse_span);          // of the keys a fused draw generates (from the draw's own arguments: the lane's sorter may have been told about a later frame's keys by now)
     Lane& L = c->lanes[a.lane];
     Framebuffer& F = c->fbs[a.fb];
     Buffer* data = getbuf(c, a.data);
@@ -460,6 +465,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
                 if (!kh) return hipfail(c, he, "sort_hist_slot");
                 tc.keys_out = (float*)K->d; tc.idx_out = nullptr /* the depth sort below makes the identity index up */; (void)I; tc.ghist = kh; tc.span = a.fuse_span; tc.err = L.host_total_dev + 4;
                 L.depth_sort.hist_bias = a.ks.bias;
+                tc.hist_rb = L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, npre, fuse_bits, true);
             }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
@@ -485,7 +491,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             const float cam[3] = { a.ks.camx, a.ks.camy, a.ks.camz };
             float view[16] = { 0 }; view[2] = a.ks.vr0; view[6] = a.ks.vr1; view[10] = a.ks.vr2; view[14] = a.ks.vr3;
             HIPCHK(c, launch_keygen(L.s, data->soa, soa_sig3(data->soa, data->soa_n, data->soa_info), data->soa_info, npre, a.ks.t, cam, view, a.ks.mode == KEYSRC_VIEWZ ? GS4D_KEY_VIEW_Z : GS4D_KEY_REF_INV_EUCLID,
-                                    (float*)L.regen_keys, L.order_copy, kh, a.ks.bias, 0xFFFFFFFFu, L.host_total_dev + 4));
+                                    (float*)L.regen_keys, L.order_copy, kh, (L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, npre, a.keybits, true)), a.ks.bias, 0xFFFFFFFFu, L.host_total_dev + 4));
             L.depth_sort.hist_bias = a.ks.bias;
             HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, L.regen_keys, L.order_copy, npre, nullptr, a.keybits, true));
         }
@@ -495,7 +501,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             // histograms) and the binning (which reads the sorted index)
             Buffer* K = getbuf(c, a.fuse_keys); Buffer* I = getbuf(c, a.fuse_idx);
             StageTimer t(c, GS4D_T_SORT);
-            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true, true));
+            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, fuse_bits, true, true));
         }
     }
     size_t want = a.instances * 2 + 65536;
@@ -512,7 +518,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             static const bool skip_sort = getenv("GS4D_ABLATE_SORT") != nullptr;      // ablation (make TUNING=1): what the frame costs without its depth sort — an upper bound for any re-scheduling of it
             if (skip_sort) { L.depth_sort.hist_pending = false; L.depth_sort.flip ^= 1; return rc; }
 #endif
-            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, L.depth_sort.hist_bits, true, true));
+            HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, npre, nullptr, fuse_bits, true, true));
         }
         return rc;
     }
@@ -606,12 +612,13 @@ int flush_order(gs4d_ctx* c) {
         uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, po.n, &he);
         if (!kh) return hipfail(c, he, "sort_hist_slot");
         StageTimer tm(c, GS4D_T_KEYGEN);
-        HIPCHK(c, launch_keygen(L.s, D->soa, soa_sig3(D->soa, D->soa_n, D->soa_info), D->soa_info, po.n, po.t, po.cam, po.view, po.key_mode, (float*)K->d, (uint32_t*)I->d, kh, po.bias, po.span, L.host_total_dev + 4));
+        L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, po.n, span_bits(po.span), true);
+        HIPCHK(c, launch_keygen(L.s, D->soa, soa_sig3(D->soa, D->soa_n, D->soa_info), D->soa_info, po.n, po.t, po.cam, po.view, po.key_mode, (float*)K->d, (uint32_t*)I->d, kh, L.depth_sort.hist_rb, po.bias, po.span, L.host_total_dev + 4));
         L.depth_sort.hist_bias = po.bias;
     }
     if (po.sorted) {
         StageTimer t(c, GS4D_T_SORT);
-        HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, po.n, nullptr, L.depth_sort.hist_bits, true));
+        HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, (uint32_t*)K->d, (uint32_t*)I->d, po.n, nullptr, span_bits(po.span), true));
     }
     return GS4D_OK;
 }
@@ -681,7 +688,7 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     { bool ordered = false; if ((e = lds_atomic_order_selftest(c->lanes[0].s, &ordered)) != hipSuccess) return bail(hipfail(c, e, "lds_atomic_order_selftest")); c->atomic_rank = ordered; }
     const int shape_knob = getenv("GS4D_SORT_SHAPE") ? atoi(getenv("GS4D_SORT_SHAPE")) : 0, rank_knob = getenv("GS4D_SORT_RANK") ? atoi(getenv("GS4D_SORT_RANK")) : 0;
     for (int i = 0; i < c->nlanes; ++i) {
-        for (SortScratch* ss : { &c->lanes[i].depth_sort, &c->lanes[i].pair_sort }) { ss->atomic_rank = c->atomic_rank; ss->shape_knob = shape_knob; ss->rank_knob = rank_knob; }
+        for (SortScratch* ss : { &c->lanes[i].depth_sort, &c->lanes[i].pair_sort }) { ss->atomic_rank = c->atomic_rank; ss->shape_knob = shape_knob; ss->rank_knob = rank_knob; ss->rb_knob = getenv("GS4D_SORT_RB") ? atoi(getenv("GS4D_SORT_RB")) : 0; }
     }
     int rc = alloc_fbs(c, width, height);
     if (rc) return bail(rc);
@@ -907,7 +914,7 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
         Lane& Lq = lane(c);
         { int rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *V, true); if (rc) return rc; }
         c->po.sorted = true;
-        c->stat_depth_passes = (uint64_t)std::max(2, (Lq.depth_sort.hist_bits + 7) / 8);
+        c->stat_depth_passes = (uint64_t)sort_plan_passes(Lq.depth_sort.hist_bits, sort_plan_rb(Lq.depth_sort, n, Lq.depth_sort.hist_bits, true));
         K->version++; V->version++;
         V->prov_valid = true; V->prov_data = Lq.kg_data; V->prov_data_ver = Lq.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = Lq.kg_bits; V->prov_ks = Lq.kg_ks; V->prov_span = Lq.kg_span;
         return GS4D_OK;
@@ -918,7 +925,7 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
     const bool have_hist = L.depth_sort.hist_pending && keys == L.kg_buf && K->version == L.kg_ver && n == L.kg_n;
     const int key_bits = have_hist ? L.depth_sort.hist_bits : 32;
-    c->stat_depth_passes = (uint64_t)std::max(2, (key_bits + 7) / 8);
+    c->stat_depth_passes = (uint64_t)sort_plan_passes(key_bits, have_hist ? L.depth_sort.hist_rb : sort_plan_rb(L.depth_sort, n, key_bits, false));
     // ... and when the payload is the identity index the same call wrote, the sorted payload is "the records in ascending (key, index)"
     const bool identity_payload = have_hist && vals == L.kg_idx && V->version == L.kg_idx_ver;
     StageTimer t(c, GS4D_T_SORT);
@@ -1015,7 +1022,7 @@ int gs4d_keygen(gs4d_ctx* c, gs4d_buf data, float t, const float cam[3], gs4d_bu
     c->po.keygen = true; c->po.sorted = false; c->po.lane = c->cur; c->po.data = data; c->po.keys = keys; c->po.idx = idx; c->po.n = n; c->po.t = t;
     c->po.cam[0] = cam[0]; c->po.cam[1] = cam[1]; c->po.cam[2] = cam[2]; c->po.key_mode = key_mode; c->po.bias = bias; c->po.span = span;
     memcpy(c->po.view, c->u.view, sizeof c->po.view);
-    L.depth_sort.hist_bits = span < (1u << 8) ? 8 : span < (1u << 16) ? 16 : span < (1u << 24) ? 24 : 32;
+    L.depth_sort.hist_bits = span_bits(span);
     K->version++; I->version++;
     L.kg_buf = keys; L.kg_ver = K->version; L.kg_n = n;
     L.kg_idx = idx; L.kg_idx_ver = I->version; L.kg_data = data; L.kg_data_ver = D->version; L.kg_bits = L.depth_sort.hist_bits; L.kg_span = span;

@@ -32,6 +32,8 @@ struct SortScratch {
     bool hist_pending = false;         // the current slot holds a histogram accumulated by a producer kernel, not yet consumed by a sort
     int acc_flip = 0;                  // which accumulator set the next launch uses (the other one it zeroes)
     int hist_bits = 32;                // host-proven width of (key - hist_bias): passes above it are not even launched
+    int hist_rb = 8;                   // digit width the producer of the pending histogram counted in (sort_plan_rb, chosen together with hist_bits)
+    int rb_knob = 0;                   // test hook GS4D_SORT_RB (8 / 9): the digit width of every sort whose tile shape allows it
     uint32_t hist_bias = 0;            // ... of (key - hist_bias): a lower bound of all keys, which makes the high digits constant (and their passes skipped)
     uint32_t epoch = 0;                // tag of the look-back words of the latest pass launch
     bool atomic_rank = false;          // LDS-atomic ranking verified on this device (lds_atomic_order_selftest)
@@ -48,6 +50,8 @@ void sort_scratch_free(SortScratch& s);
 // instead of reading them (4 bytes per key less to write for whoever produced the keys, 4 less to read here).
 hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals = false);
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
+int sort_plan_rb(const SortScratch& s, size_t n, int key_bits, bool depth_keys);      // digit width (8 or 9 bits) of a sort of key_bits-bit keys; depth_keys: bit patterns of depth keys above a host-proven lower bound
+int sort_plan_passes(int key_bits, int rb);                          // ... and the launches it takes
 hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
 // Layout of the SoA shadow (preprocess.hip).  The repack kernel verifies what a compact layout assumes, bit for bit, for every record, and
 // reports a violation in bbox[15]; the caller then repacks in the next layout down.
@@ -59,30 +63,32 @@ hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
 enum { SOA_FULL = 0, SOA_SYM = 1, SOA_STATIC3D = 2 };
 struct SoaInfo { int layout = SOA_FULL; float consts[8] = { 0 }; };      // consts: pos.w, sig[0][3], sig[1][3], sig[2][3], sig[3][0..3] of a static set
 // sig3 == nullptr: a static set (SOA_STATIC3D) — mu_t and sig[3] are info.consts for every record
-hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, const SoaInfo& info, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
+hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, const SoaInfo& info, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist, int rb,
                          uint32_t bias, uint32_t span, uint32_t* err);
 
 // ---- digit histograms for the radix sort, accumulated by whichever kernel produces the keys ----
 constexpr int OS_MAX_PASSES = 4;
 constexpr int OS_REPL = 8;                                   // replicas of the global histogram: bounds same-address atomic traffic
-constexpr size_t OS_SLOT_WORDS = (size_t)OS_REPL * OS_MAX_PASSES * 256;
+constexpr uint32_t OS_MAX_BINS = 512;                        // digits are 8 or 9 bits wide (sort_plan_rb); a histogram row always has room for 512 bins
+constexpr size_t OS_SLOT_WORDS = (size_t)OS_REPL * OS_MAX_PASSES * OS_MAX_BINS;
 #ifdef __HIPCC__
-__device__ __forceinline__ void os_hist_clear(uint32_t (*h)[256], uint32_t tid) {
+// (threads 0..255 of the workgroup call clear and flush: each looks after bins tid and tid + 256)
+__device__ __forceinline__ void os_hist_clear(uint32_t (*h)[OS_MAX_BINS], uint32_t tid) {
 #pragma unroll
-    for (int p = 0; p < OS_MAX_PASSES; ++p) h[p][tid] = 0;
+    for (int p = 0; p < OS_MAX_PASSES; ++p) { h[p][tid] = 0; h[p][tid + 256u] = 0; }
 }
 // Wave-cooperative add of one key per active lane (`in` marks the lanes that carry a key; call with the whole wave converged).
 // Skewed digits (e.g. the sign/exponent bytes of depth keys take 2-3 values) would serialise 64 LDS atomics on 2-3 addresses:
 // the lanes sharing the digit of the first unresolved lane are counted with a ballot and added by one lane, twice; the lanes
 // left after that (most lanes of a uniformly distributed digit, almost none of a skewed one) use plain LDS atomics.
-__device__ __forceinline__ void os_hist_add(uint32_t (*h)[256], uint32_t key, bool in, int passes) {
+__device__ __forceinline__ void os_hist_add(uint32_t (*h)[OS_MAX_BINS], uint32_t key, bool in, int passes, int rb) {
     const uint64_t act = __ballot(in);
     if (act == 0ull) return;
     const uint32_t lane = threadIdx.x & 63u;
 #pragma unroll
     for (int p = 0; p < OS_MAX_PASSES; ++p) {
         if (p >= passes) break;
-        const uint32_t d = (key >> (8 * p)) & 255u;
+        const uint32_t d = (key >> (rb * p)) & ((1u << rb) - 1u);
         uint64_t rem = act;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -96,9 +102,13 @@ __device__ __forceinline__ void os_hist_add(uint32_t (*h)[256], uint32_t key, bo
         if ((rem >> lane) & 1ull) atomicAdd(&h[p][d], 1u);
     }
 }
-__device__ __forceinline__ void os_hist_flush(uint32_t (*h)[256], uint32_t* __restrict__ ghist, int passes, uint32_t tid) {
-    uint32_t* g = ghist + (size_t)(blockIdx.x % OS_REPL) * OS_MAX_PASSES * 256;
-    for (int p = 0; p < passes; ++p) { const uint32_t v = h[p][tid]; if (v) atomicAdd(&g[p * 256 + tid], v); }
+__device__ __forceinline__ void os_hist_flush(uint32_t (*h)[OS_MAX_BINS], uint32_t* __restrict__ ghist, int passes, uint32_t tid) {
+    uint32_t* g = ghist + (size_t)(blockIdx.x % OS_REPL) * OS_MAX_PASSES * OS_MAX_BINS;
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t v = h[p][tid], v2 = h[p][tid + 256u];
+        if (v) atomicAdd(&g[p * OS_MAX_BINS + tid], v);
+        if (v2) atomicAdd(&g[p * OS_MAX_BINS + tid + 256u], v2);
+    }
 }
 #endif
 
@@ -124,7 +134,7 @@ struct TileCount {                               // hist == nullptr: the ordered
     KeySrc ks;
     // Fused key generation (the draw executes a gs4d_keygen + gs4d_sort_pairs that were queued just before it): the projection kernel also
     // writes the caller's key and index buffers and accumulates the digit histograms of the depth sort, exactly as k_keygen would
-    float* keys_out = nullptr; uint32_t* idx_out = nullptr; uint32_t* ghist = nullptr; uint32_t span = 0xFFFFFFFFu; uint32_t* err = nullptr;
+    float* keys_out = nullptr; uint32_t* idx_out = nullptr; uint32_t* ghist = nullptr; int hist_rb = 8; uint32_t span = 0xFFFFFFFFu; uint32_t* err = nullptr;
 };
 constexpr uint32_t V2_MAX_LIST = 1024;           // longest list the compositor sorts in LDS (beyond ~1000 entries per tile its LDS footprint costs more occupancy than the ordered path's two sort passes cost time).  Longer per-tile lists are cut into depth slabs (below); beyond V2_MAX_SLABS a draw uses the ordered path
 constexpr uint32_t V2_MAX_SLABS = 64;           // a tile's list is kept as `slabs` sub-lists by equal ranges of the blend key: far slab first, each ordered by itself in the compositor (one wave lane holds a sub-list's table entry: <= 64)

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void k_preprocess(SRC src, uint32_t n, PU u, P
 template <class SRC, bool FUSE_KEYS, bool COUNT>
 __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t n, PU u, PreOut out, TileCount tc) {
     __shared__ uint32_t h[COUNT ? 1024 : 1];
-    __shared__ uint32_t kh[FUSE_KEYS ? OS_MAX_PASSES : 1][256];
+    __shared__ uint32_t kh[FUSE_KEYS ? OS_MAX_PASSES : 1][OS_MAX_BINS];
     if (COUNT) for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) h[b] = 0u;
     if (FUSE_KEYS && threadIdx.x < 256u) os_hist_clear(kh, threadIdx.x);
     __syncthreads();
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t
                 if (key > tc.span) __hip_atomic_store(tc.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // below the bias wraps to a huge value: caught too
             }
         }
-        if (FUSE_KEYS) os_hist_add(kh, key, i < i1, OS_MAX_PASSES);
+        if (FUSE_KEYS) os_hist_add(kh, key, i < i1, OS_MAX_PASSES, tc.hist_rb);
         if (COUNT) count_buckets(h, tc.nb - 1u, (uint32_t)tc.tiles_x, r);
     }
     __syncthreads();

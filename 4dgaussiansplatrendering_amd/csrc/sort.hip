@@ -25,10 +25,10 @@ namespace gs4d {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, const float4* __restrict__ sig3, uint32_t n, float t,
                                                 float camx, float camy, float camz, float4 vrow2 /* view row 2: V[2],V[6],V[10],V[14] */, int key_mode,
-                                                float* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ ghist /* digit histograms of (key - bias), for the sort */,
+                                                float* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t* __restrict__ ghist /* digit histograms of (key - bias), for the sort */, int rb /* ... in digits of rb bits */,
                                                 uint32_t bias /* host-proven lower bound of every key's bit pattern */, uint32_t span /* ... and of (key - bias) from above */, uint32_t* __restrict__ err,
                                                 float4 csig3, float cmut /* sig3 == nullptr (a static set: SOA_STATIC3D): sig[3] and mu_t of every record */) {
-    __shared__ uint32_t h[OS_MAX_PASSES][256];
+    __shared__ uint32_t h[OS_MAX_PASSES][OS_MAX_BINS];
     os_hist_clear(h, threadIdx.x);
     __syncthreads();
     for (uint32_t i0 = blockIdx.x * 256u; i0 < n; i0 += gridDim.x * 256u) {      // uniform trip count per workgroup
@@ -58,18 +58,18 @@ __global__ __launch_bounds__(256) void k_keygen(const float4* __restrict__ pos, 
         }
         const uint32_t kb = __float_as_uint(key);
         if (in && (kb < bias || kb - bias > span)) __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the bound did not hold: reported, never silently mis-sorted
-        os_hist_add(h, kb - bias, in, OS_MAX_PASSES);
+        os_hist_add(h, kb - bias, in, OS_MAX_PASSES, rb);
     }
     __syncthreads();
     os_hist_flush(h, ghist, OS_MAX_PASSES, threadIdx.x);
 }
 
-hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, const SoaInfo& info, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist,
+hipError_t launch_keygen(hipStream_t st, const float4* pos, const float4* sig3, const SoaInfo& info, size_t n, float t, const float cam[3], const float view[16], int key_mode, float* keys, uint32_t* idx, uint32_t* ghist, int rb,
                          uint32_t bias, uint32_t span, uint32_t* err) {
     if (n == 0) return hipSuccess;
     float4 vr = make_float4(view[2], view[6], view[10], view[14]);
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 1024);     // grid-stride: bounds the histogram flush to 1024 workgroups
-    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist, bias, span, err,
+    k_keygen<<<dim3(blocks), dim3(256), 0, st>>>(pos, sig3, (uint32_t)n, t, cam[0], cam[1], cam[2], vr, key_mode, keys, idx, ghist, rb, bias, span, err,
                                                      make_float4(info.consts[4], info.consts[5], info.consts[6], info.consts[7]), info.consts[0]);
     return hipGetLastError();
 }
@@ -114,9 +114,9 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, uint32_t lane
     for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off, 64); if (lane >= (unsigned)off) v += t; }
     return v;
 }
-__global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int passes,
-                                                 uint32_t* __restrict__ ghist /* [OS_REPL][4][256], zero on entry */) {
-    __shared__ uint32_t h[OS_MAX_PASSES][256];
+__global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ keys, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int passes, int rb,
+                                                 uint32_t* __restrict__ ghist /* [OS_REPL][4][OS_MAX_BINS], zero on entry */) {
+    __shared__ uint32_t h[OS_MAX_PASSES][OS_MAX_BINS];
     const uint32_t n = n_dev ? min(*n_dev, n_cap) : n_cap;
     const uint32_t tid = threadIdx.x;
     os_hist_clear(h, tid);
@@ -131,11 +131,11 @@ __global__ __launch_bounds__(256) void k_os_hist(const uint32_t* __restrict__ ke
         for (int u = 0; u < 4; ++u) { const uint32_t i = i0 + u * stride; in[u] = i < nvec; kk[u] = in[u] ? k4[i] : make_uint4(0, 0, 0, 0); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            os_hist_add(h, kk[u].x, in[u], passes); os_hist_add(h, kk[u].y, in[u], passes);
-            os_hist_add(h, kk[u].z, in[u], passes); os_hist_add(h, kk[u].w, in[u], passes);
+            os_hist_add(h, kk[u].x, in[u], passes, rb); os_hist_add(h, kk[u].y, in[u], passes, rb);
+            os_hist_add(h, kk[u].z, in[u], passes, rb); os_hist_add(h, kk[u].w, in[u], passes, rb);
         }
     }
-    if (blockIdx.x == 0) { const bool in = tid < (n & 3u); os_hist_add(h, in ? keys[nvec * 4u + tid] : 0u, in, passes); }      // tail keys
+    if (blockIdx.x == 0) { const bool in = tid < (n & 3u); os_hist_add(h, in ? keys[nvec * 4u + tid] : 0u, in, passes, rb); }      // tail keys
     __syncthreads();
     os_hist_flush(h, ghist, passes, tid);
 }
@@ -178,20 +178,20 @@ __device__ __forceinline__ bool os_tpublished(uint32_t w, uint32_t epoch) { retu
 // TB/s — and the stores everybody is waiting for queue up behind it.
 
 // rows hi-k0 .. hi-(rows-1) of the tile words are outstanding and row hi-k0 is known to be missing
-template <int LB>
+template <int LB, int BINS>
 __device__ __forceinline__ uint32_t os_tiles_finish(const uint32_t* st, int32_t hi, int rows, int k0, uint32_t sum, uint32_t tid, uint32_t epoch, uint32_t* err) {
     uint32_t spins = 0;
     while (true) {
         while (true) {
             __builtin_amdgcn_s_sleep(8);
-            const uint32_t w = __hip_atomic_load(st + (size_t)(hi - k0) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t w = __hip_atomic_load(st + (size_t)(hi - k0) * (uint32_t)BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (os_tpublished(w, epoch)) { sum += w & 0x3FFFu; break; }
             if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return sum; }
         }
         if (++k0 >= rows) return sum;
         uint32_t sv[LB];
 #pragma unroll
-        for (int k = 0; k < LB; ++k) sv[k] = (k >= k0 && k < rows) ? __hip_atomic_load(st + (size_t)(hi - k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (int k = 0; k < LB; ++k) sv[k] = (k >= k0 && k < rows) ? __hip_atomic_load(st + (size_t)(hi - k) * (uint32_t)BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         bool missing = false;
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
@@ -204,20 +204,20 @@ __device__ __forceinline__ uint32_t os_tiles_finish(const uint32_t* st, int32_t 
 }
 
 // accumulator rows t+k0 .. t+rows-1 are outstanding and row t+k0 is known to be incomplete (complete = `expect` arrivals)
-template <int LB>
+template <int LB, int BINS>
 __device__ __forceinline__ uint32_t os_acc_finish(const uint32_t* acc, uint32_t t, int rows, int k0, uint32_t sum, uint32_t expect, uint32_t tid, uint32_t* err) {
     uint32_t spins = 0;
     while (true) {
         while (true) {
             __builtin_amdgcn_s_sleep(8);
-            const uint32_t w = __hip_atomic_load(acc + (size_t)(t + k0) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t w = __hip_atomic_load(acc + (size_t)(t + k0) * (uint32_t)BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((w >> 24) == expect) { sum += w & 0xFFFFFFu; break; }
             if (++spins > (1u << 20)) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return sum; }
         }
         if (++k0 >= rows) return sum;
         uint32_t sv[LB];
 #pragma unroll
-        for (int k = 0; k < LB; ++k) sv[k] = (k >= k0 && k < rows) ? __hip_atomic_load(acc + (size_t)(t + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (int k = 0; k < LB; ++k) sv[k] = (k >= k0 && k < rows) ? __hip_atomic_load(acc + (size_t)(t + k) * (uint32_t)BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         bool missing = false;
 #pragma unroll
         for (int k = 0; k < LB; ++k) {
@@ -230,6 +230,7 @@ __device__ __forceinline__ uint32_t os_acc_finish(const uint32_t* acc, uint32_t 
 }
 
 // Exclusive prefix of tile `tile` for digit `tid`: earlier tiles of its group + earlier groups of its super-group + earlier super-groups.
+template <int BINS>
 __device__ __forceinline__ uint32_t os_lookback(const uint32_t* st, const uint32_t* acc, uint32_t acc_groups, uint32_t tile, uint32_t tid, uint32_t epoch, uint32_t* err) {
     const uint32_t grp = tile / OS_GROUP, sup = grp / OS_SUPER;
     const int rows_t = (int)(tile - grp * OS_GROUP), rows_g = (int)(grp - sup * OS_SUPER);
@@ -237,9 +238,9 @@ __device__ __forceinline__ uint32_t os_lookback(const uint32_t* st, const uint32
     const uint32_t g0 = sup * OS_SUPER;
     uint32_t tv[OS_GROUP], gv[OS_SUPER];
 #pragma unroll
-    for (int k = 0; k < (int)OS_GROUP; ++k) tv[k] = k < rows_t ? __hip_atomic_load(st + (size_t)(hi - k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    for (int k = 0; k < (int)OS_GROUP; ++k) tv[k] = k < rows_t ? __hip_atomic_load(st + (size_t)(hi - k) * (uint32_t)BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 #pragma unroll
-    for (int k = 0; k < (int)OS_SUPER; ++k) gv[k] = k < rows_g ? __hip_atomic_load(acc + (size_t)(g0 + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    for (int k = 0; k < (int)OS_SUPER; ++k) gv[k] = k < rows_g ? __hip_atomic_load(acc + (size_t)(g0 + k) * (uint32_t)BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     uint32_t sum_t = 0, sum_g = 0, sum_s = 0;
     int miss_t = -1, miss_g = -1;
 #pragma unroll
@@ -255,12 +256,12 @@ __device__ __forceinline__ uint32_t os_lookback(const uint32_t* st, const uint32
         sum_g += gv[k] & 0xFFFFFFu;
     }
     // earlier super-groups (sorts of more than 1024 tiles only), 16 at a time
-    const uint32_t* sacc = acc + (size_t)acc_groups * 256u;
+    const uint32_t* sacc = acc + (size_t)acc_groups * (uint32_t)BINS;
     for (uint32_t t = 0; t < sup; t += 16u) {
         const int rows = (int)min(16u, sup - t);
         uint32_t sv[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) sv[k] = k < rows ? __hip_atomic_load(sacc + (size_t)(t + k) * 256u + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        for (int k = 0; k < 16; ++k) sv[k] = k < rows ? __hip_atomic_load(sacc + (size_t)(t + k) * (uint32_t)BINS + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
         int miss = -1;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -268,47 +269,49 @@ __device__ __forceinline__ uint32_t os_lookback(const uint32_t* st, const uint32
             if ((sv[k] >> 24) != OS_SUPER) { miss = k; continue; }
             sum_s += sv[k] & 0xFFFFFFu;
         }
-        if (miss >= 0) sum_s = os_acc_finish<16>(sacc, t, rows, miss, sum_s, OS_SUPER, tid, err);
+        if (miss >= 0) sum_s = os_acc_finish<16, BINS>(sacc, t, rows, miss, sum_s, OS_SUPER, tid, err);
     }
-    if (miss_t >= 0) sum_t = os_tiles_finish<(int)OS_GROUP>(st, hi, rows_t, miss_t, sum_t, tid, epoch, err);
-    if (miss_g >= 0) sum_g = os_acc_finish<(int)OS_SUPER>(acc, g0, rows_g, miss_g, sum_g, OS_GROUP, tid, err);
+    if (miss_t >= 0) sum_t = os_tiles_finish<(int)OS_GROUP, BINS>(st, hi, rows_t, miss_t, sum_t, tid, epoch, err);
+    if (miss_g >= 0) sum_g = os_acc_finish<(int)OS_SUPER, BINS>(acc, g0, rows_g, miss_g, sum_g, OS_GROUP, tid, err);
     return sum_t + sum_g + sum_s;
 }
 
-// exclusive scan of one value per digit (threads 0..255 carry a value, all THREADS threads take part in the barriers)
-template <int THREADS>
-__device__ __forceinline__ uint32_t digit_excl_scan(uint32_t v, uint32_t* tmp /* __shared__[4] */, uint32_t tid) {
+// exclusive scan of one value per digit (threads 0..BINS-1 carry a value, all THREADS threads take part in the barriers)
+template <int THREADS, int BINS>
+__device__ __forceinline__ uint32_t digit_excl_scan(uint32_t v, uint32_t* tmp /* __shared__[BINS / 64] */, uint32_t tid) {
     const uint32_t lane = tid & 63u, w = tid >> 6;
-    const uint32_t inc = wave_incl_scan_u32(tid < 256u ? v : 0u, lane);
+    const uint32_t inc = wave_incl_scan_u32(tid < (uint32_t)BINS ? v : 0u, lane);
     __syncthreads();
-    if (lane == 63u && w < 4u) tmp[w] = inc;
+    if (lane == 63u && w < (uint32_t)(BINS / 64)) tmp[w] = inc;
     __syncthreads();
     uint32_t base = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) if ((unsigned)k < w) base += tmp[k];
+    for (int k = 0; k < BINS / 64 - 1; ++k) if ((unsigned)k < w) base += tmp[k];
     return base + inc - v;
 }
 
 // Persistent workgroups: the grid is what fits the device at once (or one workgroup per tile if that is fewer); a workgroup draws a
 // ticket, sorts that tile, draws the next.  What does not depend on the tile (histograms -> live passes and digit bases, the
 // housekeeping for the next launch) happens once per workgroup, and a finished tile's successor starts without a dispatch.
-template <int THREADS, int ITEMS, bool ATOMIC_RANK>
+template <int THREADS, int ITEMS, bool ATOMIC_RANK, int RB>
 __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap, const uint32_t* __restrict__ n_dev, int pass, int passes,
-                                                     const uint32_t* __restrict__ ghist /* [OS_REPL][4][256] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
-                                                     uint32_t* status /* [tiles][256] */, uint32_t* acc /* [acc_groups + supers][256], zero at launch */, uint32_t* acc_next /* zeroed here */, uint32_t acc_groups, uint32_t acc_words,
+                                                     const uint32_t* __restrict__ ghist /* [OS_REPL][4][OS_MAX_BINS] */, uint32_t* __restrict__ ghist_other /* zeroed by pass 0 */,
+                                                     uint32_t* status /* [tiles][BINS] */, uint32_t* acc /* [acc_groups + supers][BINS], zero at launch */, uint32_t* acc_next /* zeroed here */, uint32_t acc_groups, uint32_t acc_words,
                                                      uint32_t epoch, uint32_t* err,
                                                      uint32_t* ticket /* zero at launch */, uint32_t* ticket_next /* zeroed here */, uint32_t bias, int identity_vals /* the payload is the identity index and has NOT been written: see radix_sort_pairs */,
                                                      u64* stamps /* tuning aid, may be null */) {
     constexpr uint32_t TILE_KEYS = THREADS * ITEMS;
     constexpr int WAVES = THREADS / 64;
+    constexpr uint32_t BINS = 1u << RB;                      // digits of RB bits: thread d < BINS owns digit d in everything per digit below
+    static_assert(BINS <= (uint32_t)THREADS && BINS <= OS_MAX_BINS && BINS >= 64u, "one thread per digit");
     static_assert(TILE_KEYS < (1u << 14), "tile-level look-back words carry 14-bit counts");
     static_assert((uint64_t)TILE_KEYS * OS_GROUP * OS_SUPER < (1u << 24) && OS_GROUP < 256u && OS_SUPER < 256u, "accumulators are {arrivals:8, sum:24}");
     __shared__ uint32_t skeys[TILE_KEYS];
     __shared__ uint32_t svals[TILE_KEYS];
-    __shared__ uint32_t wcnt[WAVES][256];
-    __shared__ uint32_t loff[256];      // first local slot of digit d in the reordered tile
-    __shared__ uint32_t gpos[256];      // global slot of that first element
-    __shared__ uint32_t s_tmp[4];
+    __shared__ uint32_t wcnt[WAVES][BINS];
+    __shared__ uint32_t loff[BINS];     // first local slot of digit d in the reordered tile
+    __shared__ uint32_t gpos[BINS];     // global slot of that first element
+    __shared__ uint32_t s_tmp[BINS / 64];
     __shared__ uint32_t s_dead;          // bit q: one digit of pass q holds every key (the pass is a stable identity)
     __shared__ uint32_t s_tile;
 
@@ -321,13 +324,13 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     if (tid == 1u) s_dead = 0u;
     if (tid == 2u && blockIdx.x == 0) __hip_atomic_store(ticket_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the next launch on this stream counts from zero again
-    for (uint32_t q = tid; q < WAVES * 256u; q += THREADS) (&wcnt[0][0])[q] = 0u;
+    for (uint32_t q = tid; q < WAVES * BINS; q += THREADS) (&wcnt[0][0])[q] = 0u;
     uint32_t tot = 0, dead = 0;
-    if (tid < 256u) {
+    if (tid < BINS) {
         for (int q = 0; q < passes; ++q) {
             uint32_t g = 0;
 #pragma unroll
-            for (int r = 0; r < OS_REPL; ++r) g += ghist[(r * OS_MAX_PASSES + q) * 256 + tid];
+            for (int r = 0; r < OS_REPL; ++r) g += ghist[(r * OS_MAX_PASSES + q) * OS_MAX_BINS + tid];
             if (q == pass) tot = g;
             if (g == n) dead |= 1u << q;                          // one digit holds every key
         }
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
     __syncthreads();
     uint32_t tile = s_tile;
     if (tile >= ntiles) return;                                   // uniform
-    const int shift = 8 * pass;
+    const int shift = RB * pass;
     int src, dst, executed, total;
     if (!os_schedule(~s_dead, passes, pass, src, dst, executed, total)) {          // uniform: this pass is an identity
         // an identity payload nobody has written, and no pass at all will move anything (every key is the same): pass 0's launch writes it
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
             key[j] = valid ? keys_in[i] : 0xFFFFFFFFu;
             val[j] = !valid ? 0u : make_identity ? i : vals_in[i];
         }
-        if (first) { digit_base = digit_excl_scan<THREADS>(tot, s_tmp, tid); first = false; }      // once per workgroup, under the first tile's loads
+        if (first) { digit_base = digit_excl_scan<THREADS, (int)BINS>(tot, s_tmp, tid); first = false; }      // once per workgroup, under the first tile's loads
         OS_STAMP(1);
 
         if (ATOMIC_RANK) {
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const bool valid = (wbase + j * 64u + lane) < n;
-                const uint32_t d = ((key[j] - bias) >> shift) & 255u;
+                const uint32_t d = ((key[j] - bias) >> shift) & (BINS - 1u);
                 rank[j] = valid ? atomicAdd(&wcnt[w][d], 1u) : 0u;
             }
         } else {
@@ -386,10 +389,10 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
 #pragma unroll
             for (int j = 0; j < ITEMS; ++j) {
                 const bool valid = (wbase + j * 64u + lane) < n;
-                const uint32_t d = ((key[j] - bias) >> shift) & 255u;
+                const uint32_t d = ((key[j] - bias) >> shift) & (BINS - 1u);
                 uint64_t m = __ballot(valid);
 #pragma unroll
-                for (int b = 0; b < 8; ++b) {
+                for (int b = 0; b < RB; ++b) {
                     const bool bit = (d >> b) & 1u;
                     const uint64_t bal = __ballot(bit);
                     m &= bit ? bal : ~bal;
@@ -409,39 +412,39 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         uint32_t cnt = 0;
         uint32_t garr = 0;
         const uint32_t grp = tile / OS_GROUP, sup = grp / OS_SUPER;
-        if (tid < 256u) {
+        if (tid < BINS) {
 #pragma unroll
             for (int k = 0; k < WAVES; ++k) { const uint32_t t = wcnt[k][tid]; wcnt[k][tid] = cnt; cnt += t; }
-            __hip_atomic_store(status + (size_t)tile * 256u + tid, os_tword(epoch, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(status + (size_t)tile * BINS + tid, os_tword(epoch, cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // {arrivals:8, sum:24} accumulator of the group (only if a later tile will read it); what it held before comes back after the
             // reorder below
             // (asked for only where a super-group total will be needed: waiting for the returned value costs a memory round trip)
-            if (sup + 1u < nsuper) garr = __hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1u << 24) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else if (grp + 1u < ngroups) (void)__hip_atomic_fetch_add(acc + (size_t)grp * 256u + tid, (1u << 24) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sup + 1u < nsuper) garr = __hip_atomic_fetch_add(acc + (size_t)grp * BINS + tid, (1u << 24) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (grp + 1u < ngroups) (void)__hip_atomic_fetch_add(acc + (size_t)grp * BINS + tid, (1u << 24) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         OS_STAMP(2);
         // local run starts, then the reorder inside LDS — none of it needs the other tiles, so it overlaps their publishing
-        const uint32_t lo_ = digit_excl_scan<THREADS>(cnt, s_tmp, tid);
-        if (tid < 256u) loff[tid] = lo_;
+        const uint32_t lo_ = digit_excl_scan<THREADS, (int)BINS>(cnt, s_tmp, tid);
+        if (tid < BINS) loff[tid] = lo_;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             if ((wbase + j * 64u + lane) < n) {                   // stable: wave-major, item-major, lane order == memory order
-                const uint32_t d = ((key[j] - bias) >> shift) & 255u;
+                const uint32_t d = ((key[j] - bias) >> shift) & (BINS - 1u);
                 const uint32_t l = loff[d] + wcnt[w][d] + rank[j];
                 skeys[l] = key[j];
                 svals[l] = val[j];
             }
         }
         OS_STAMP(3);
-        if (tid < 256u) {
+        if (tid < BINS) {
             // the tile that completes its group (per digit: whichever arrived sixteenth) hands the group's total to the super-group: a
             // super-group's accumulator takes OS_SUPER additions per digit, not one from every tile under it
             if (sup + 1u < nsuper && (garr >> 24) == OS_GROUP - 1u)
-                (void)__hip_atomic_fetch_add(acc + (size_t)(acc_groups + sup) * 256u + tid, (1u << 24) | ((garr & 0xFFFFFFu) + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(acc + (size_t)(acc_groups + sup) * BINS + tid, (1u << 24) | ((garr & 0xFFFFFFu) + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // look back, one memory round trip: the tiles of this group before this one (their words), the groups of this super-group
             // before this group and the super-groups before this one (their accumulators, complete when every member has arrived)
-            const uint32_t prefix = os_lookback(status, acc, acc_groups, tile, tid, epoch, err);
+            const uint32_t prefix = os_lookback<(int)BINS>(status, acc, acc_groups, tile, tid, epoch, err);
             gpos[tid] = digit_base + prefix;
         }
         __syncthreads();
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
             const uint32_t l = j * THREADS + tid;
             if (l < tcount) {
                 const uint32_t k = skeys[l];
-                const uint32_t d = ((k - bias) >> shift) & 255u;
+                const uint32_t d = ((k - bias) >> shift) & (BINS - 1u);
                 const uint32_t o = gpos[d] + (l - loff[d]);
                 // Small sorts (one round of tiles): streaming stores, the runs go to memory as they are written instead of sitting dirty in
                 // this XCD's L2 until the end-of-kernel write-back.  Large sorts (the 8192-key shape, several rounds of tiles per workgroup):
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
                 // without gs4d_buffer_invalidate — the two no longer describe the same array and `o` can point anywhere.  One compare keeps
                 // the store inside the buffer and turns the contract violation into the error word (the frame is reported as failed).
                 if (o >= n) { __hip_atomic_store(err, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); continue; }
-                if (ITEMS >= 16) { keys_out[o] = k; vals_out[o] = svals[l]; }
+                if (ITEMS >= 12) { keys_out[o] = k; vals_out[o] = svals[l]; }
                 else { __builtin_nontemporal_store(k, keys_out + o); __builtin_nontemporal_store(svals[l], vals_out + o); }
             }
         }
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(THREADS) void k_os_pass(OsBufs bufs, uint32_t n_cap
         if (tid == 0) next = atomicAdd(ticket, 1u);
         __syncthreads();                                          // everybody is done with the tile's LDS
         if (tid == 0) s_tile = next;
-        for (uint32_t q = tid; q < WAVES * 256u; q += THREADS) (&wcnt[0][0])[q] = 0u;
+        for (uint32_t q = tid; q < WAVES * BINS; q += THREADS) (&wcnt[0][0])[q] = 0u;
         __syncthreads();
         tile = s_tile;
         if (tile >= ntiles) return;                               // uniform; every workgroup ends on a ticket past the last tile
@@ -533,10 +536,10 @@ hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n) {
         s.vals2 = s.keys2 + 2 * n;
         s.cap = n;
     }
-    // control block: two [OS_REPL][4][256] histogram slots (alternating), then the 64-bit look-back words [tiles + groups][256]
+    // control block: two [OS_REPL][4][OS_MAX_BINS] histogram slots (alternating), then the look-back words [tiles + groups][bins], sized for the widest digit
     const size_t tiles = (s.cap + 1023) / 1024;      // smallest tile = 1024 keys; sized for the largest sort seen (the layout depends on it)
     const size_t groups = tiles / OS_GROUP + 2, supers = groups / OS_SUPER + 2;
-    const size_t words = 2 * OS_SLOT_WORDS + (tiles + 2 + 2 * 2 * (groups + supers)) * 256;       // tile words (u32), two accumulator sets (u64)
+    const size_t words = 2 * OS_SLOT_WORDS + (tiles + 2 + 2 * 2 * (groups + supers)) * OS_MAX_BINS;       // tile words, two accumulator sets
     if (s.hist_cap < words) {
         uint32_t* nh = nullptr;
         if ((e = hipMalloc(&nh, words * 4)) != hipSuccess) return e;
@@ -574,7 +577,7 @@ uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError
     return s.hist + (s.flip ? OS_SLOT_WORDS : 0);
 }
 
-template <int THREADS, int ITEMS, bool ATOMIC_RANK>
+template <int THREADS, int ITEMS, bool ATOMIC_RANK, int RB>
 static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist, bool identity_vals) {
     const uint32_t tile_keys = THREADS * ITEMS;
     const uint32_t tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
@@ -582,7 +585,7 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     static uint32_t resident = 0;
     if (!resident) {
         int per_cu = 0, dev = 0; hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_os_pass<THREADS, ITEMS, ATOMIC_RANK>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_os_pass<THREADS, ITEMS, ATOMIC_RANK, RB>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
         resident = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
     }
@@ -595,7 +598,7 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     if (!have_hist) {
         if (s.hist_pending) { if ((e = hipMemsetAsync(ghist, 0, OS_SLOT_WORDS * 4, st)) != hipSuccess) return e; }   // someone else's histogram sits in the slot
         const uint32_t hist_blocks = (uint32_t)std::min<size_t>((n / 16 + 255) / 256 + 1, 256);          // few workgroups: each flushes 256 global atomics per pass
-        k_os_hist<<<dim3(hist_blocks), dim3(256), 0, st>>>(keys, (uint32_t)n, n_dev, passes, ghist);
+        k_os_hist<<<dim3(hist_blocks), dim3(256), 0, st>>>(keys, (uint32_t)n, n_dev, passes, RB, ghist);
     }
     s.hist_pending = false;
     s.flip ^= 1;
@@ -610,8 +613,8 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     uint32_t* status = s.hist + 2 * OS_SLOT_WORDS;
     // accumulator sets sit behind the tile words of the LARGEST sort this scratch was sized for (so they never move between launches)
     const size_t cap_tiles = (s.cap + 1023) / 1024, cap_groups = cap_tiles / OS_GROUP + 2, cap_supers = cap_groups / OS_SUPER + 2;
-    const size_t acc_words = (cap_groups + cap_supers) * 256;
-    uint32_t* acc_base = status + (cap_tiles + 2) * 256;
+    const size_t acc_words = (cap_groups + cap_supers) * OS_MAX_BINS;
+    uint32_t* acc_base = status + (cap_tiles + 2) * OS_MAX_BINS;
     OsBufs b;
     b.k[0] = keys; b.v[0] = vals;
     b.k[1] = s.keys2; b.v[1] = s.vals2;
@@ -622,7 +625,7 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
             if ((e = hipMemsetAsync(status, 0, (s.hist_cap - 2 * OS_SLOT_WORDS) * 4, st)) != hipSuccess) return e;
             ++s.epoch;
         }
-        k_os_pass<THREADS, ITEMS, ATOMIC_RANK><<<dim3(grid), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, acc_base + (s.acc_flip ? acc_words : 0), acc_base + (s.acc_flip ? 0 : acc_words), (uint32_t)cap_groups, (uint32_t)acc_words,
+        k_os_pass<THREADS, ITEMS, ATOMIC_RANK, RB><<<dim3(grid), dim3(THREADS), 0, st>>>(b, (uint32_t)n, n_dev, p, passes, ghist, ghist_other, status, acc_base + (s.acc_flip ? acc_words : 0), acc_base + (s.acc_flip ? 0 : acc_words), (uint32_t)cap_groups, (uint32_t)acc_words,
                                                                          s.epoch & 0x3FFFFFFFu,
                                                                          s.err ? s.err : s.totals, s.totals + 64 + (s.acc_flip ? 1 : 0), s.totals + 64 + (s.acc_flip ? 0 : 1), bias, identity_vals ? 1 : 0, (stampf && p == stamp_pass) ? stamps : nullptr);
         s.acc_flip ^= 1;
@@ -638,29 +641,50 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
     return hipGetLastError();
 }
 
+// Digit width of a sort of `key_bits`-bit keys: 9-bit digits (512 bins) where they save a pass over 8-bit ones — 17-18 and 25-27 key bits, e.g. the
+// depth keys of slowly moving (4D) splats, whose host-proven span is a little wider than 2^24; the tile shape needs a thread per bin.
+int sort_plan_rb(const SortScratch& s, size_t n, int key_bits, bool depth_keys) {
+    (void)n;
+    if (s.rb_knob == 8 || s.rb_knob == 9) return (s.rb_knob == 9 && (s.shape_knob == 1 || s.shape_knob == 4)) ? 8 : s.rb_knob;      // test hook (the 256-thread shapes have no 512-bin form)
+    if (s.shape_knob == 1 || s.shape_knob == 4) return 8;
+    const int p8 = std::max(2, (key_bits + 7) / 8), p9 = std::max(2, (key_bits + 8) / 9);
+    // (Beyond 27 bits both take four launches.  Preferring 9-bit digits there — their last digit is bits 27-31 only and is skipped on the device when
+    // no key reaches 2^27 above the bias — was measured on the 4D sweep of BASELINE.json configs[3], whose bound is open-ended: 39.36 against 39.26 ms, nothing.)
+    (void)depth_keys;
+    return p9 < p8 ? 9 : 8;
+}
+int sort_plan_passes(int key_bits, int rb) { return std::min(OS_MAX_PASSES, std::max(2, (key_bits + rb - 1) / rb)); }      // an even number of executed passes always exists (see os_schedule)
+
 hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals) {
     if (n <= 1) { if (n == 1 && identity_vals) return hipMemsetAsync(vals, 0, 4, st); return hipSuccess; }      // radix_sort.hpp:260
     if (n >= (1ull << 32) - 1) return hipErrorInvalidValue;
     hipError_t e = sort_scratch_reserve(st, s, n);
     if (e != hipSuccess) return e;
-    int passes = (key_bits + 7) / 8;
-    if (passes < 2) passes = 2;                       // an even number of executed passes always exists (see os_schedule)
+    // the producer of the histograms (have_hist) counted digits of s.hist_rb bits: whoever set hist_bits chose it with sort_plan_rb
+    const int rb = have_hist ? s.hist_rb : sort_plan_rb(s, n, key_bits, false);
+    if (rb != 8 && rb != 9) return hipErrorInvalidValue;
+    const int passes = sort_plan_passes(key_bits, rb);
     // 8192-key tiles: 1024 threads x 8 keys (streaming stores) for small sorts, 512 x 16 (ordinary stores) beyond 1.5M keys.  Alone, a pass over
     // 10^6 keys costs the same with 4096-key tiles of 512 threads (12.7 us either way, round 3); with four frame lanes overlapping the
     // larger tile — half as many workgroups waiting in the look-back beside the other lanes' kernels — gives 2-3 % more frames per second
     // (0.1153 against 0.1184 ms per frame, two runs each); 2048-key tiles are slower alone (20.3 us) and overlapped (0.1405).
-    const int shape = s.shape_knob ? s.shape_knob : (n <= ((size_t)3 << 19) ? 3 : 5);
+    // 512 bins: the large sorts use 512 x 12 (48 KB of keys and values + 16 KB of per-wave counters: still two workgroups per CU).
+    int shape = s.shape_knob ? s.shape_knob : (n <= ((size_t)3 << 19) ? 3 : 5);
+    if (rb == 9 && shape == 5 && !s.shape_knob) shape = 6;
     const bool atomic_rank = s.rank_knob ? s.rank_knob == 2 : s.atomic_rank;
-#define GS4D_OS(T, I) (atomic_rank ? onesweep<T, I, true>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals) : onesweep<T, I, false>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals))
+#define GS4D_OS8(T, I) (atomic_rank ? onesweep<T, I, true, 8>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals) : onesweep<T, I, false, 8>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals))
+#define GS4D_OS(T, I) (rb == 9 ? (atomic_rank ? onesweep<T, I, true, 9>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals) : onesweep<T, I, false, 9>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals)) : GS4D_OS8(T, I))
     switch (shape) {
-    case 1: return GS4D_OS(256, 8);
+    case 1: return rb == 8 ? GS4D_OS8(256, 8) : hipErrorInvalidValue;
     case 2: return GS4D_OS(512, 8);
     case 3: return GS4D_OS(1024, 8);
-    case 4: return GS4D_OS(256, 16);
+    case 4: return rb == 8 ? GS4D_OS8(256, 16) : hipErrorInvalidValue;
     case 5: return GS4D_OS(512, 16);
+    case 6: return GS4D_OS(512, 12);
     default: return GS4D_OS(512, 4);
     }
 #undef GS4D_OS
+#undef GS4D_OS8
 }
 
 } // namespace gs4d

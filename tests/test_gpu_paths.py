@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _ctx(gs4d, W, H, monkeypatch, **env):
-    for k in ("GS4D_DRAW_PATH", "GS4D_SORT_RANK", "GS4D_SORT_SHAPE"):
+    for k in ("GS4D_DRAW_PATH", "GS4D_SORT_RANK", "GS4D_SORT_SHAPE", "GS4D_SORT_RB"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
@@ -216,10 +216,90 @@ def test_view_z_key_mode(gs4d, oracle, monkeypatch, path):
     assert (st["unordered_draws"] > 0) == (path == "auto")
 
 
+def test_tile_sort_of_a_4k_frame_takes_two_passes(gs4d, oracle, monkeypatch):
+    """The instance-ordered path sorts its entries by tile id: 129 600 tiles at 3840 x 2160 are 17 bits — three passes of 8-bit digits, two of
+    9-bit ones (k_bin_emit counts the digits the sort will use).  Same image either way, and the checker's."""
+    n, W, H = 60000, 3840, 2160
+    pos, q, sc, rgba = scenes.cube_params(n, seed=13)
+    rec = gs4d.build_records_3d(pos, q, sc * 2.0, rgba)
+    cam = scenes.CAM_CUBE
+    view, proj = cam_mats(gs4d, cam, W, H)
+    imgs = {}
+    for rb, passes in ((0, 2), (8, 3)):
+        ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_DRAW_PATH="ordered", **({"GS4D_SORT_RB": rb} if rb else {}))
+        img, perm, keys, st = _sorted_frame(ctx, gs4d, rec, cam, view, proj)
+        assert st["tile_sort_passes"] == passes and st["unordered_draws"] == 0, st
+        ctx.close()
+        imgs[rb] = img
+    assert np.array_equal(imgs[0], imgs[8])
+    eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    assert np.array_equal(perm, eperm)
+    assert linf(imgs[0], eimg) <= TOL
+
+
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("path", ["auto", "ordered"])
+def test_nine_bit_digits_for_wide_key_spans(gs4d, oracle, monkeypatch, path, fuse):
+    """Moving (4D) splats: the host-proven span of the depth keys covers the motion and is wider than 2^24 bit patterns (25 bits here) — four
+    passes of 8-bit digits, THREE of 9-bit ones (sort.hip sort_plan_rb).  Keys, permutation (bit-exact against the stable sort of the reference's keys) and image
+    on both draw paths, with the keys generated by the draw (the projection kernel counts the 9-bit digits) and by k_keygen."""
+    n, W, H = 150000, 960, 540
+    pos4, q, sc, life, fade, vel, rgba = scenes.cube_params_4d(n, seed=71)
+    rec = gs4d.build_records_4d(pos4, q, sc * 3.0, life, fade, vel * 0.3, rgba)      # (at full speed the extrapolated positions reach the camera: no upper bound for the keys at all)
+    cam, t = scenes.CAM_CUBE, 21.5
+    view, proj = cam_mats(gs4d, cam, W, H)
+    env = {"GS4D_FUSE_KEYGEN": fuse}
+    if path == "ordered":
+        env["GS4D_DRAW_PATH"] = "ordered"
+    ctx = _ctx(gs4d, W, H, monkeypatch, **env)
+    db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    for _ in range(2):                                             # twice: the second frame reuses the sorter's alternating histogram slots
+        ctx.clear()
+        ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+        ctx.keygen(db, t, cam[0], kb, ib, n)
+        ctx.sort_pairs(kb, ib, n)
+        ctx.set_mode(gs4d.MODE_4D_SORTED)
+        ctx.bind(1, ib)
+        ctx.bind(2, db)
+        ctx.draw_instanced(n)
+        img = ctx.read_pixels()
+        st = ctx.stats()
+        assert st["depth_sort_passes"] == 3, st
+        eidx, ekeys = oracle.keygen(rec, t, cam[0])
+        sk, perm = ctx.read(kb, np.uint32, n), ctx.read(ib, np.uint32, n)
+        esk, eperm = oracle.sort_pairs(ekeys.view(np.uint32), eidx, "std")
+        assert np.array_equal(sk, esk) and np.array_equal(perm, eperm)
+        eproj = oracle.preprocess(oracle.MODE_4D, rec, view, proj, W, H, t, 0.0)
+        eimg = oracle.composite(eproj, eperm, oracle.MODE_4D, W, H, oracle.clear_image(W, H))
+        assert linf(img, eimg) <= TOL
+    assert (st["unordered_draws"] > 0) == (path == "auto")
+    ctx.close()
+    # the same frame with 8-bit digits forced: four passes (the span is wider than 2^24), same result
+    ctx = _ctx(gs4d, W, H, monkeypatch, GS4D_SORT_RB=8, **env)
+    db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.clear()
+    ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+    ctx.keygen(db, t, cam[0], kb, ib, n)
+    ctx.sort_pairs(kb, ib, n)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+    ctx.bind(1, ib)
+    ctx.bind(2, db)
+    ctx.draw_instanced(n)
+    img8 = ctx.read_pixels()
+    assert ctx.stats()["depth_sort_passes"] == 4
+    assert np.array_equal(ctx.read(ib, np.uint32, n), eperm) and np.array_equal(img8, img)
+    ctx.close()
+    monkeypatch.delenv("GS4D_FUSE_KEYGEN", raising=False)
+
+
 @pytest.mark.parametrize("rank", [1, 2])
-@pytest.mark.parametrize("shape", [1, 2, 3, 4, 5, 6])
-def test_sort_ranking_variants_and_tile_shapes(gs4d, oracle, monkeypatch, rank, shape):
-    ctx = _ctx(gs4d, 64, 64, monkeypatch, GS4D_SORT_RANK=rank, GS4D_SORT_SHAPE=shape)
+@pytest.mark.parametrize("shape,rb", [(1, 8), (2, 8), (3, 8), (4, 8), (5, 8), (6, 8), (7, 8), (2, 9), (3, 9), (5, 9), (6, 9), (7, 9)])
+def test_sort_ranking_variants_and_tile_shapes(gs4d, oracle, monkeypatch, rank, shape, rb):
+    """Every tile shape of a pass (threads x keys per thread), both rankings, and both digit widths: 8 bits (256 bins, four passes over
+    32-bit keys) and 9 bits (512 bins, one thread per bin: the shapes of 512 threads and more; 4 x 9 bits cover the 32)."""
+    ctx = _ctx(gs4d, 64, 64, monkeypatch, GS4D_SORT_RANK=rank, GS4D_SORT_SHAPE=shape, GS4D_SORT_RB=rb)
     rng = np.random.default_rng(100 * rank + shape)
     for n, distinct in ((70001, 0), (262144 + 5, 37)):
         keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
@@ -254,12 +334,14 @@ def test_sort_ranking_variants_and_tile_shapes(gs4d, oracle, monkeypatch, rank, 
     ctx.close()
 
 
+@pytest.mark.parametrize("rb", [8, 9])
 @pytest.mark.parametrize("n", [100003, 1 << 20])
 @pytest.mark.parametrize("pattern", ["byte0", "byte1", "byte2", "byte3", "bytes0and3"])
-def test_sort_with_one_live_digit(gs4d, oracle, monkeypatch, n, pattern):
+def test_sort_with_one_live_digit(gs4d, oracle, monkeypatch, n, pattern, rb):
     """Keys that differ in ONE byte only: three of the four digit passes are identities, and the schedule has to add exactly one
-    copying pass so that the result lands in the caller's buffers (the round-1 race was here: waves could disagree about it)."""
-    ctx = _ctx(gs4d, 64, 64, monkeypatch)
+    copying pass so that the result lands in the caller's buffers (the round-1 race was here: waves could disagree about it).  With 9-bit
+    digits a byte of the key straddles two digits (two live passes) or sits inside one."""
+    ctx = _ctx(gs4d, 64, 64, monkeypatch, GS4D_SORT_RB=rb)
     rng = np.random.default_rng(n % 1000)
     base = np.uint32(0x3A5C7E91)
     sh = {"byte0": (0,), "byte1": (8,), "byte2": (16,), "byte3": (24,), "bytes0and3": (0, 24)}[pattern]

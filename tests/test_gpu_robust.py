@@ -317,6 +317,47 @@ def test_static_3d_record_shadow(gs4d, oracle, monkeypatch, fuse):
         assert linf(img2, eimg2) <= TOL
 
 
+def test_record_shadow_follows_buffer_updates(gs4d, oracle, monkeypatch):
+    """The layout of the private shadow is decided per upload: a static set that gets one moving record through gs4d_buffer_subdata is
+    repacked in a layout that can hold it (and back), and every frame is the reference's."""
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    from test_gpu_render import cam_mats
+    n, W, H = 12000, 640, 360
+    pos, q, sc, rgba = scenes.cube_params(n, seed=9)
+    rec = gs4d.build_records_3d(pos, q, sc * 3.0, rgba)
+    cam, t = scenes.CAM_CUBE, 2.0
+    view, proj = cam_mats(gs4d, cam, W, H)
+    ctx = gs4d.Context(W, H)
+    db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.set_mode(gs4d.MODE_4D_SORTED)
+
+    def frame(r):
+        ctx.clear()
+        ctx.set_uniforms(time=t, min_opacity=0.0, view=view, proj=proj)
+        ctx.keygen(db, t, cam[0], kb, ib, n)
+        ctx.sort_pairs(kb, ib, n)
+        ctx.bind(1, ib)
+        ctx.bind(2, db)
+        ctx.draw_instanced(n)
+        img = ctx.read_pixels()
+        eimg, eperm, _ = oracle.render_4d(r, True, t, 0.0, cam[0], view, proj, W, H)
+        assert linf(img, eimg) <= TOL
+        assert np.array_equal(ctx.read(ib, np.uint32, n), eperm)
+        return ctx.stats()["record_read_bytes"]
+
+    assert frame(rec) == 64
+    rec2 = rec.copy()
+    rec2[n // 3, 3] = 1.5                                          # one record gets a time of its own ...
+    rec2[n // 3, 20:23] = (4.0, -3.0, 2.0)                         # ... and moves: sig[3].xyz (what the key loop extrapolates with, Scenes.h:30-33)
+    rec2[n // 3, 8 + 3], rec2[n // 3, 12 + 3], rec2[n // 3, 16 + 3] = 4.0, -3.0, 2.0
+    ctx.subdata(db, rec2)
+    assert frame(rec2) in (72, 96)
+    ctx.subdata(db, rec)
+    assert frame(rec) == 64
+    ctx.close()
+
+
 @pytest.mark.parametrize("rename", [1, 0])
 def test_one_key_pair_for_all_frames(gs4d, oracle, monkeypatch, rename):
     """The reference's buffer layout — ONE key buffer and ONE index buffer for every frame (Scenes.h m_key_buf / m_values_buf) — with frames
