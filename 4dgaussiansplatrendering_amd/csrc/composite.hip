@@ -53,10 +53,23 @@ __global__ __launch_bounds__(256) void k_pack_rgba8(const float4* __restrict__ f
     const bool have = tstate[(y / (uint32_t)TILE) * tiles_x + x / (uint32_t)TILE] == epoch;
     out[i] = pack8(have ? fb[i] : c);
 }
+// W % 4 == 0: four pixels of a row per thread (they share a tile: TILE % 4 == 0), 64 bytes in, 16 out
+__global__ __launch_bounds__(256) void k_pack_rgba8_x4(const float4* __restrict__ fb, const uint32_t* __restrict__ tstate, uint32_t epoch, float4 c, uint32_t W, uint32_t nquads, uint32_t tiles_x, uint4* __restrict__ out) {
+    static_assert(TILE % 4 == 0, "a quad of pixels lies in one tile");
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    if (q >= nquads) return;
+    const uint32_t i = q * 4u, x = i % W, y = i / W;
+    const bool have = tstate[(y / (uint32_t)TILE) * tiles_x + x / (uint32_t)TILE] == epoch;
+    float4 v0 = c, v1 = c, v2 = c, v3 = c;
+    if (have) { v0 = fb[i]; v1 = fb[i + 1u]; v2 = fb[i + 2u]; v3 = fb[i + 3u]; }
+    out[q] = make_uint4(pack8(v0), pack8(v1), pack8(v2), pack8(v3));
+}
 
 hipError_t launch_pack_rgba8(hipStream_t st, const float4* fb, const uint32_t* tstate, uint32_t epoch, const float clear[4], int W, int H, int tiles_x, uint32_t* out) {
     const size_t npix = (size_t)W * H;
-    k_pack_rgba8<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st>>>(fb, tstate, epoch, make_float4(clear[0], clear[1], clear[2], clear[3]), (uint32_t)W, (uint32_t)npix, (uint32_t)tiles_x, out);
+    const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
+    if (W % 4 == 0 && ((uintptr_t)out & 15u) == 0) k_pack_rgba8_x4<<<dim3((unsigned)((npix / 4 + 255) / 256)), dim3(256), 0, st>>>(fb, tstate, epoch, c, (uint32_t)W, (uint32_t)(npix / 4), (uint32_t)tiles_x, (uint4*)out);
+    else k_pack_rgba8<<<dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st>>>(fb, tstate, epoch, c, (uint32_t)W, (uint32_t)npix, (uint32_t)tiles_x, out);
     return hipGetLastError();
 }
 

@@ -16,6 +16,7 @@
 // the list agrees are skipped.  Keys that tie are rare (24-bit depth keys, tens of entries): the list is sorted on the key alone and
 // checked for equal neighbours; only then is it sorted on the record index first and on the key again.
 #include "composite_common.h"
+#include <cstdlib>
 
 namespace gs4d {
 
@@ -158,7 +159,10 @@ hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* 
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid(composite_grid(tiles_x, tiles_y));
-    const int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
+    int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
+#ifdef GS4D_TUNING
+    { static const bool nosort = getenv("GS4D_V2_NOSORT") != nullptr; if (nosort) kp = rp = 0; }      // ablation: what the wave-local list sort costs the kernel (the image is then wrong)
+#endif
     return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs)
                      : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs);
 }

@@ -358,6 +358,34 @@ def test_record_shadow_follows_buffer_updates(gs4d, oracle, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("W,H,offset", [(640, 360, 0), (640, 360, 4), (62, 30, 0), (66, 41, 8)])
+def test_rgba8_pack_any_width_and_alignment(gs4d, monkeypatch, W, H, offset):
+    """gs4d_read_pixels_rgba8_device: four pixels per thread when the row length and the destination allow it, one otherwise; the bytes are
+    the same — round(clamp(x) * 255) of the float image, clear colour where nothing was drawn (tiles that are not in memory)."""
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    n = 3000
+    pos, q, sc, rgba = scenes.cube_params(n, seed=17)
+    rec = gs4d.build_records_3d(pos * 0.5, q, sc * 4.0, rgba)
+    cam = scenes.CAM_CUBE
+    view, proj = cam_mats(gs4d, cam, W, H)
+    ctx = gs4d.Context(W, H)
+    db, ob = ctx.buffer(rec), ctx.buffer(nbytes=W * H * 4 + 64)
+    ctx.set_clear_color((0.25, 0.5, 0.75, 1.0))
+    ctx.clear()
+    ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+    ctx.set_mode(gs4d.MODE_4D_DIRECT)
+    ctx.bind(1, db)
+    ctx.draw_instanced(n)
+    ctx.read_pixels_rgba8_device(ctx.device_ptr(ob)[0] + offset, W * H * 4)
+    ctx.finish()
+    got = ctx.read(ob, np.uint8, W * H * 4, offset=offset).reshape(H, W, 4).astype(np.int32)
+    img = ctx.read_pixels()
+    ctx.close()
+    want = np.rint(np.clip(img, 0.0, 1.0) * 255.0).astype(np.int32)
+    assert np.array_equal(got, want)
+    assert np.any(np.all(want == np.array([64, 128, 191, 255]), axis=2)) and np.any(np.any(want != np.array([64, 128, 191, 255]), axis=2))      # clear tiles and drawn ones
+
+
 @pytest.mark.parametrize("rename", [1, 0])
 def test_one_key_pair_for_all_frames(gs4d, oracle, monkeypatch, rename):
     """The reference's buffer layout — ONE key buffer and ONE index buffer for every frame (Scenes.h m_key_buf / m_values_buf) — with frames
