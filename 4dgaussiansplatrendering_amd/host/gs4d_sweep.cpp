@@ -201,7 +201,10 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     HIPOK(hipMalloc(&dmax, sizeof(double) * (size_t)(2 * world + 2)));
     HIPOK(hipMemset(dmax, 0, sizeof(double) * (size_t)(2 * world + 2)));
     // comm-stream accounting: a pair of timing events around every gather of a sweep
-    const int max_gathers = (most + G - 1) / G + 1;
+    // a gather after every full batch and, inside the last batch of a sweep, after every quarter of one (sharding.py gather_schedule: what is on
+    // the wire when a rank's last frame has been rendered is then a quarter of a batch)
+    const int piece = G / 4 < 1 ? 1 : G / 4, last_batch = most > 0 ? (most - 1) / G : 0;
+    const int max_gathers = (most + G - 1) / G + G / piece + 1;
     std::vector<hipEvent_t> g0(max_gathers), g1(max_gathers);
     for (int i = 0; i < max_gathers; ++i) { HIPOK(hipEventCreate(&g0[i])); HIPOK(hipEventCreate(&g1[i])); }
     int gathers_this_sweep = 0;
@@ -221,13 +224,14 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         GSOK(gs4d_draw_instanced(ctx, n));
         return 0;
     };
-    auto gather = [&](int batch_no, bool verify) -> int {
+    auto gather = [&](int batch_no, int lo, int hi, bool verify) -> int {      // slots [lo, hi) of batch `batch_no`
         const int x = batch_no & 1;
+        const size_t off = (size_t)lo * fbytes, len = (size_t)(hi - lo) * fbytes;
         const int gi = gathers_this_sweep < max_gathers ? gathers_this_sweep : max_gathers - 1;
         HIPOK(hipEventRecord(g0[gi], stream));
         NCCLOK(ncclGroupStart());
-        if (rank == 0) { for (int r = 1; r < world; ++r) NCCLOK(ncclRecv(gathered[x] + (size_t)r * G * fbytes, G * fbytes, ncclUint8, r, comm, stream)); }
-        else NCCLOK(ncclSend(batch[x], G * fbytes, ncclUint8, 0, comm, stream));
+        if (rank == 0) { for (int r = 1; r < world; ++r) NCCLOK(ncclRecv(gathered[x] + (size_t)r * G * fbytes + off, len, ncclUint8, r, comm, stream)); }
+        else NCCLOK(ncclSend(batch[x] + off, len, ncclUint8, 0, comm, stream));
         NCCLOK(ncclGroupEnd());
         HIPOK(hipEventRecord(g1[gi], stream));
         ++gathers_this_sweep;
@@ -238,7 +242,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
             HIPOK(hipMemcpyAsync(host_frames.data(), gathered[x], host_frames.size(), hipMemcpyDeviceToHost, stream));
             HIPOK(hipStreamSynchronize(stream));
             for (int r = 0; r < world; ++r)
-                for (int p = 0; p < G; ++p) {
+                for (int p = lo; p < hi; ++p) {
                     const int k = r + (batch_no * G + p) * world;            // slot p of rank r's batch holds its frame batch_no * G + p
                     if (batch_no * G + p >= most || k >= a.frames) continue;
                     const uint8_t* f = host_frames.data() + ((size_t)r * G + p) * fbytes;
@@ -251,13 +255,17 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         return 0;
     };
     auto sweep = [&](bool verify) -> int {
-        int presented = 0;
+        int presented = 0, slot_lo = 0;
         gathers_this_sweep = 0;
         auto present = [&](int j, int frames_back) -> int {
             const int x = (presented / G) & 1;
             if (j < (int)mine.size()) GSOK(gs4d_read_frame_rgba8_device_after(ctx, frames_back, batch[x] + (size_t)(presented % G) * fbytes, fbytes, ev_valid[x] ? (void*)ev_free[x] : nullptr));
             ++presented;
-            if (presented % G == 0 || presented == most) { if (gather((presented - 1) / G, verify)) return 1; }
+            const int b = (presented - 1) / G, hi = (presented - 1) % G + 1;
+            if (presented % G == 0 || presented == most || (b == last_batch && hi % piece == 0)) {
+                if (gather(b, slot_lo, hi, verify)) return 1;
+                slot_lo = presented % G == 0 ? 0 : hi;
+            }
             return 0;
         };
         for (int j = 0; j < most; ++j) {

@@ -28,6 +28,24 @@ def gather_frames(dist, frame, gathered, dst=0):
     return gathered
 
 
+def gather_schedule(most, every):
+    """When a rank gathers during a sweep of `most` presentations into batch buffers of `every` slots, and which slots travel:
+    a list of (presentations so far, batch number, first slot, one past the last slot).  A gather after every full batch — and, inside the
+    LAST batch, after every max(1, every // 4) presentations: what is still on the wire when a rank's last frame has been rendered is then
+    a quarter of a batch, not a whole one (a batch of 8 RGBA8 1080p frames is 66 MB: about a millisecond of one xGMI link, a fifth of an
+    8-GPU sweep).  Every rank runs the same schedule (all ranks count `most` presentations), so the collective calls match."""
+    every = max(1, int(every))
+    piece = max(1, every // 4)
+    last = (most - 1) // every if most > 0 else 0
+    out, lo = [], 0
+    for p in range(1, most + 1):
+        b, hi = (p - 1) // every, (p - 1) % every + 1
+        if p % every == 0 or p == most or (b == last and hi % piece == 0):
+            out.append((p, b, lo, hi))
+            lo = 0 if p % every == 0 else hi
+    return out
+
+
 # ---- single-frame sharding by tile rows -----------------------------------------------------------------------------------------
 TILE = 8
 

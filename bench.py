@@ -346,12 +346,13 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
     free_ev = [torch.cuda.Event(), torch.cuda.Event()]
     free_valid = [False, False]
     pipelined = ctx.stats()["lanes"] >= 2                                 # with one frame lane there is no previous image to read
+    schedule = {p: (b, lo, hi) for p, b, lo, hi in sharding.gather_schedule(most, G)}      # after how many presentations a gather goes out, and which slots of its batch
     comm = {"busy_ms": 0.0, "tail_ms": 0.0, "pairs": []}
 
     def sweep(_k):
         """One step: this rank's frames of the 256-frame sweep.  Presentation is software-pipelined as a swap chain is — frame j is queued
         first, then frame j-1 (the previous image) is packed to RGBA8 into the batch — and every G presented frames the batch is gathered
-        on rank 0.  Every rank counts `most` presentations (a rank with one frame fewer skips the read of its last slot), so all ranks
+        on rank 0 (the last batch of the sweep in quarters: sharding.gather_schedule).  Every rank counts `most` presentations (a rank with one frame fewer skips the read of its last slot), so all ranks
         make the same collective calls whatever the world size."""
         state = {"p": 0}
 
@@ -360,10 +361,12 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
             if j < len(mine):
                 ctx.read_frame_rgba8_device_after(frames_back, batch[x][state["p"] % G].data_ptr(), H * W * 4, free_ev[x].cuda_event if free_valid[x] else None)
             state["p"] += 1
-            if state["p"] % G == 0 or state["p"] == most:
+            if state["p"] in schedule:
+                _b, lo, hi = schedule[state["p"]]
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(comm_stream)
-                sharding.gather_frames(dist, batch[x] if backend == "nccl" else batch[x].cpu(), gathered[x], dst=0)
+                part = batch[x][lo:hi]
+                sharding.gather_frames(dist, part if backend == "nccl" else part.cpu(), [g[lo:hi] for g in gathered[x]] if rank == 0 else None, dst=0)
                 e1.record(comm_stream)
                 free_ev[x].record(comm_stream)
                 free_valid[x] = True

@@ -129,24 +129,38 @@ def test_band_layout_of_the_tile_row_sharding():
 
 def test_sweep_schedule_matches_the_sharding_helpers():
     """gs4d_sweep.cpp: rank r renders frames r, r + N, ...; slot p of its batch b holds its frame b * G + p; every rank presents
-    ceil(F / N) times.  The same mapping as sharding.frames_for_rank / bench.py's N > 1 leg."""
+    ceil(F / N) times; a gather after every full batch and, inside the last batch, after every quarter (sharding.gather_schedule — the
+    program's loop is restated here beside it).  The same mapping as sharding.frames_for_rank / bench.py's N > 1 leg."""
     import importlib
     sharding = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
-    for F, N, G in [(256, 8, 8), (256, 3, 8), (7, 2, 4), (5, 8, 2), (256, 1, 8)]:
+    for F, N, G in [(256, 8, 8), (256, 3, 8), (7, 2, 4), (5, 8, 2), (256, 1, 8), (256, 8, 3), (30, 4, 16), (9, 1, 1)]:
         most = (F + N - 1) // N
+        piece, last_batch = max(1, G // 4), (most - 1) // G
+        sched = sharding.gather_schedule(most, G)
+        # the C++ loop (gs4d_sweep.cpp sweep()/present()), restated
+        mine_sched, slot_lo = [], 0
+        for presented in range(1, most + 1):
+            b, hi = (presented - 1) // G, (presented - 1) % G + 1
+            if presented % G == 0 or presented == most or (b == last_batch and hi % piece == 0):
+                mine_sched.append((presented, b, slot_lo, hi))
+                slot_lo = 0 if presented % G == 0 else hi
+        assert mine_sched == sched
+        assert len(sched) <= (most + G - 1) // G + G // piece + 1          # the program's event capacity
+        # every slot of every batch travels exactly once, in order, and never before it has been packed
+        slots = [(b, q) for _, b, lo, hi in sched for q in range(lo, hi)]
+        assert slots == [((p - 1) // G, (p - 1) % G) for p in range(1, most + 1)]
+        assert all(hi <= (p - 1) % G + 1 and b == (p - 1) // G for p, b, lo, hi in sched)
+        # what is still to be sent after the last presentation is at most a quarter of a batch
+        assert sched[-1][0] == most and sched[-1][3] - sched[-1][2] <= piece
         seen = {}
         for r in range(N):
             mine = list(range(r, F, N))
             assert mine == list(sharding.frames_for_rank(F, r, N))
-            presented = 0
-            for j in range(most):                                  # one presentation per step, a gather after every G and at the end
-                presented += 1
-                if presented % G == 0 or presented == most:
-                    b = (presented - 1) // G
-                    for p in range(G):
-                        k = r + (b * G + p) * N
-                        if b * G + p < most and k < F:
-                            assert k not in seen
-                            seen[k] = (r, b, p)
-                            assert b * G + p < len(mine) and mine[b * G + p] == k
+            for _, b, lo, hi in sched:
+                for p in range(lo, hi):
+                    k = r + (b * G + p) * N
+                    if b * G + p < most and k < F:
+                        assert k not in seen
+                        seen[k] = (r, b, p)
+                        assert b * G + p < len(mine) and mine[b * G + p] == k
         assert sorted(seen) == list(range(F))
