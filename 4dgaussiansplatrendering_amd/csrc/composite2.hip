@@ -5,11 +5,11 @@
 // composite_chunk().  What differs is where the blend order comes from.  tilelist.hip leaves every tile an UNORDERED list of
 // (key, record) entries; "instance order" — the order the reference's ROP blends in — is ascending (key, record) (KeySrc,
 // gs4d_internal.h).  The wave reads its whole list into registers (PER entries per lane; k_bucket_tiles guarantees it fits, otherwise the
-// draw was aborted and re-run on the ordered path), sorts it with a wave-local LSD radix sort over 6-bit digits — 64 counters, one
+// draw was aborted and re-run on the ordered path), sorts it with a wave-local LSD radix sort over 8-bit digits — 256 counters, four
 // per lane — and then walks it from the end (front-most) as composite.hip does.
 //
-// Radix pass, one wave, no other wave to wait for: count the digit with no-return LDS atomics, exclusive wave scan of the 64
-// counters, then a RETURNING LDS atomic add on the digit's running position gives every element its slot.  That is stable because
+// Radix pass, one wave, no other wave to wait for: count the digit with no-return LDS atomics, exclusive scan of the 256
+// counters (inside each lane, then across the wave), then a RETURNING LDS atomic add on the digit's running position gives every element its slot.  Stable because
 // (a) the LDS unit serialises the lanes of one instruction that hit the same counter in ascending lane order — verified on the device
 // at context creation (lds_atomic_order_selftest; the unordered path is not used if the test fails) — and (b) a wave's LDS
 // instructions execute in program order, so element j*64+lane is ranked before element (j+1)*64+lane'.  Digits on which every key of
@@ -20,31 +20,42 @@
 
 namespace gs4d {
 
+constexpr int WS_DIGIT_BITS = 8;                                   // digit of the wave-local sort: 256 counters, four per lane (6-bit digits, one counter per lane, take four passes over 24-bit keys instead of three)
+constexpr int WS_BINS = 1 << WS_DIGIT_BITS, WS_CPL = WS_BINS / 64; // counters per lane
+
 template <int PER>
 struct WaveSort {
     uint32_t k[PER], r[PER];
 
-    __device__ __forceinline__ void pass(bool on_rec, int shift, uint32_t E, uint32_t* ek, uint32_t* er, uint32_t* cnt, uint32_t lane) {
-        cnt[lane] = 0u;
+    __device__ __forceinline__ void pass(bool on_rec, int shift, uint32_t E, uint32_t* ek, uint32_t* er, uint32_t* cnt /* [WS_BINS] */, uint32_t lane) {
+#pragma unroll
+        for (int q = 0; q < WS_CPL; ++q) cnt[q * 64 + lane] = 0u;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             if ((uint32_t)j * 64u >= E) break;                                     // uniform
-            if ((uint32_t)j * 64u + lane < E) { const uint32_t d = ((on_rec ? r[j] : k[j]) >> shift) & 63u; __hip_atomic_fetch_add(&cnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            if ((uint32_t)j * 64u + lane < E) { const uint32_t d = ((on_rec ? r[j] : k[j]) >> shift) & (uint32_t)(WS_BINS - 1); __hip_atomic_fetch_add(&cnt[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
         }
         __syncthreads();
-        const uint32_t c = cnt[lane];
-        if (__ballot(c == E) != 0ull) return;                                      // uniform: one digit holds every key — a stable identity
-        uint32_t inc = c;
+        // lane l owns counters l * WS_CPL .. l * WS_CPL + WS_CPL - 1 (consecutive digits): exclusive scan inside the lane, then across the wave
+        static_assert(WS_CPL == 4, "a lane's counters are read and written as one uint4");
+        const uint4 cc = reinterpret_cast<const uint4*>(cnt)[lane];
+        const uint32_t c[WS_CPL] = { cc.x, cc.y, cc.z, cc.w };
+        const uint32_t sum = (cc.x + cc.y) + (cc.z + cc.w);
+        const bool all = cc.x == E || cc.y == E || cc.z == E || cc.w == E;
+        if (__ballot(all) != 0ull) return;                                         // uniform: one digit holds every key — a stable identity
+        uint32_t inc = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += t; }
-        cnt[lane] = inc - c;
+        uint32_t run = inc - sum;
+        __syncthreads();                                                            // (everybody has read the counts)
+        reinterpret_cast<uint4*>(cnt)[lane] = make_uint4(run, run + c[0], run + c[0] + c[1], run + c[0] + c[1] + c[2]);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             if ((uint32_t)j * 64u >= E) break;
             if ((uint32_t)j * 64u + lane < E) {
-                const uint32_t d = ((on_rec ? r[j] : k[j]) >> shift) & 63u;
+                const uint32_t d = ((on_rec ? r[j] : k[j]) >> shift) & (uint32_t)(WS_BINS - 1);
                 const uint32_t dest = atomicAdd(&cnt[d], 1u);                      // lane-ordered within the instruction, program-ordered across j
                 ek[dest] = k[j]; er[dest] = r[j];
             }
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
     __shared__ __attribute__((aligned(16))) uint32_t sh_a[SHARED_WORDS];
     __shared__ uint32_t pmask[64 * 2];
-    __shared__ uint32_t cnt[64];
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[WS_BINS];
     __shared__ uint32_t er[64 * PER];
     float4* stage = reinterpret_cast<float4*>(sh_a);
     uint32_t* ek = sh_a;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
                 ws.k[j] = 0u; ws.r[j] = 0u;
                 if ((uint32_t)j * 64u + lane < E) { const uint2 e = entries[start + j * 64 + lane]; ws.k[j] = e.x; ws.r[j] = e.y; }
             }
-            for (int p = 0; p < key_passes; ++p) ws.pass(false, 6 * p, E, ek, er, cnt, lane);
+            for (int p = 0; p < key_passes; ++p) ws.pass(false, WS_DIGIT_BITS * p, E, ek, er, cnt, lane);
             // the sorted keys go to LDS for the neighbour test (the last pass may have been an identity that wrote nothing)
 #pragma unroll
             for (int j = 0; j < PER; ++j) { if ((uint32_t)j * 64u + lane < E) { ek[j * 64 + lane] = ws.k[j]; er[j * 64 + lane] = ws.r[j]; } }
@@ -108,8 +119,8 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
             for (int j = 0; j < PER; ++j) { const uint32_t i = (uint32_t)j * 64u + lane; if (i + 1u < E) tie |= ek[i] == ek[i + 1u]; }
             if (__ballot(tie) != 0ull) {                    // equal keys: instance order among them is ascending record index
                 __syncthreads();
-                for (int p = 0; p < rec_passes; ++p) ws.pass(true, 6 * p, E, ek, er, cnt, lane);
-                for (int p = 0; p < key_passes; ++p) ws.pass(false, 6 * p, E, ek, er, cnt, lane);
+                for (int p = 0; p < rec_passes; ++p) ws.pass(true, WS_DIGIT_BITS * p, E, ek, er, cnt, lane);
+                for (int p = 0; p < key_passes; ++p) ws.pass(false, WS_DIGIT_BITS * p, E, ek, er, cnt, lane);
 #pragma unroll
                 for (int j = 0; j < PER; ++j) { if ((uint32_t)j * 64u + lane < E) er[j * 64 + lane] = ws.r[j]; }
             }
@@ -159,7 +170,7 @@ hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* 
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
     const dim3 grid(composite_grid(tiles_x, tiles_y));
-    int kp = (keybits + 5) / 6, rp = (recbits + 5) / 6;
+    int kp = (keybits + WS_DIGIT_BITS - 1) / WS_DIGIT_BITS, rp = (recbits + WS_DIGIT_BITS - 1) / WS_DIGIT_BITS;
 #ifdef GS4D_TUNING
     { static const bool nosort = getenv("GS4D_V2_NOSORT") != nullptr; if (nosort) kp = rp = 0; }      // ablation: what the wave-local list sort costs the kernel (the image is then wrong)
 #endif
