@@ -342,7 +342,7 @@ int enqueue_raster(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, cons
     const size_t ntiles = (size_t)c->tiles_x * c->tiles_y;
     int tile_bits = 1; while (((size_t)1 << tile_bits) < ntiles) ++tile_bits;
     // (4K: 129 600 tiles = 17 bits — three passes of 8-bit digits, two of 9-bit ones)
-    const int tile_rb = L.pair_sort.hist_rb = sort_plan_rb(L.pair_sort, L.pair_cap, tile_bits, false), tile_passes = sort_plan_passes(tile_bits, tile_rb);
+    const int tile_rb = L.pair_sort.hist_rb = sort_plan_rb(L.pair_sort, L.pair_cap, tile_bits), tile_passes = sort_plan_passes(tile_bits, tile_rb);
     {
         StageTimer t(c, GS4D_T_BINNING);
         hipError_t he = hipSuccess;
@@ -465,7 +465,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
                 if (!kh) return hipfail(c, he, "sort_hist_slot");
                 tc.keys_out = (float*)K->d; tc.idx_out = nullptr /* the depth sort below makes the identity index up */; (void)I; tc.ghist = kh; tc.span = a.fuse_span; tc.err = L.host_total_dev + 4;
                 L.depth_sort.hist_bias = a.ks.bias;
-                tc.hist_rb = L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, npre, fuse_bits, true);
+                tc.hist_rb = L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, npre, fuse_bits);
             }
             if (a.quads) HIPCHK(c, launch_preprocess_3d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
             else if (a.mode == GS4D_MODE_2D) HIPCHK(c, launch_preprocess_2d(L.s, (const float*)data->d, npre, a.u, c->W, c->H, po, tc));
@@ -490,8 +490,9 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             if (!kh) return hipfail(c, he, "sort_hist_slot");
             const float cam[3] = { a.ks.camx, a.ks.camy, a.ks.camz };
             float view[16] = { 0 }; view[2] = a.ks.vr0; view[6] = a.ks.vr1; view[10] = a.ks.vr2; view[14] = a.ks.vr3;
+            L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, npre, a.keybits);
             HIPCHK(c, launch_keygen(L.s, data->soa, soa_sig3(data->soa, data->soa_n, data->soa_info), data->soa_info, npre, a.ks.t, cam, view, a.ks.mode == KEYSRC_VIEWZ ? GS4D_KEY_VIEW_Z : GS4D_KEY_REF_INV_EUCLID,
-                                    (float*)L.regen_keys, L.order_copy, kh, (L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, npre, a.keybits, true)), a.ks.bias, 0xFFFFFFFFu, L.host_total_dev + 4));
+                                    (float*)L.regen_keys, L.order_copy, kh, L.depth_sort.hist_rb, a.ks.bias, 0xFFFFFFFFu, L.host_total_dev + 4));
             L.depth_sort.hist_bias = a.ks.bias;
             HIPCHK(c, radix_sort_pairs(L.s, L.depth_sort, L.regen_keys, L.order_copy, npre, nullptr, a.keybits, true));
         }
@@ -612,7 +613,7 @@ int flush_order(gs4d_ctx* c) {
         uint32_t* kh = sort_hist_slot(L.s, L.depth_sort, po.n, &he);
         if (!kh) return hipfail(c, he, "sort_hist_slot");
         StageTimer tm(c, GS4D_T_KEYGEN);
-        L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, po.n, span_bits(po.span), true);
+        L.depth_sort.hist_rb = sort_plan_rb(L.depth_sort, po.n, span_bits(po.span));
         HIPCHK(c, launch_keygen(L.s, D->soa, soa_sig3(D->soa, D->soa_n, D->soa_info), D->soa_info, po.n, po.t, po.cam, po.view, po.key_mode, (float*)K->d, (uint32_t*)I->d, kh, L.depth_sort.hist_rb, po.bias, po.span, L.host_total_dev + 4));
         L.depth_sort.hist_bias = po.bias;
     }
@@ -914,7 +915,7 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
         Lane& Lq = lane(c);
         { int rc = lane_access(c, *K, true); if (rc) return rc; rc = lane_access(c, *V, true); if (rc) return rc; }
         c->po.sorted = true;
-        c->stat_depth_passes = (uint64_t)sort_plan_passes(Lq.depth_sort.hist_bits, sort_plan_rb(Lq.depth_sort, n, Lq.depth_sort.hist_bits, true));
+        c->stat_depth_passes = (uint64_t)sort_plan_passes(Lq.depth_sort.hist_bits, sort_plan_rb(Lq.depth_sort, n, Lq.depth_sort.hist_bits));
         K->version++; V->version++;
         V->prov_valid = true; V->prov_data = Lq.kg_data; V->prov_data_ver = Lq.kg_data_ver; V->prov_ver = V->version; V->prov_n = n; V->prov_bits = Lq.kg_bits; V->prov_ks = Lq.kg_ks; V->prov_span = Lq.kg_span;
         return GS4D_OK;
@@ -925,7 +926,7 @@ int gs4d_sort_pairs(gs4d_ctx* c, gs4d_buf keys, gs4d_buf vals, size_t n) {
     // k_keygen leaves the digit histograms of the keys it wrote: no histogram launch when this sort is of exactly those keys
     const bool have_hist = L.depth_sort.hist_pending && keys == L.kg_buf && K->version == L.kg_ver && n == L.kg_n;
     const int key_bits = have_hist ? L.depth_sort.hist_bits : 32;
-    c->stat_depth_passes = (uint64_t)sort_plan_passes(key_bits, have_hist ? L.depth_sort.hist_rb : sort_plan_rb(L.depth_sort, n, key_bits, false));
+    c->stat_depth_passes = (uint64_t)sort_plan_passes(key_bits, have_hist ? L.depth_sort.hist_rb : sort_plan_rb(L.depth_sort, n, key_bits));
     // ... and when the payload is the identity index the same call wrote, the sorted payload is "the records in ascending (key, index)"
     const bool identity_payload = have_hist && vals == L.kg_idx && V->version == L.kg_idx_ver;
     StageTimer t(c, GS4D_T_SORT);

@@ -50,7 +50,7 @@ void sort_scratch_free(SortScratch& s);
 // instead of reading them (4 bytes per key less to write for whoever produced the keys, 4 less to read here).
 hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int key_bits, bool have_hist, bool identity_vals = false);
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
-int sort_plan_rb(const SortScratch& s, size_t n, int key_bits, bool depth_keys);      // digit width (8 or 9 bits) of a sort of key_bits-bit keys; depth_keys: bit patterns of depth keys above a host-proven lower bound
+int sort_plan_rb(const SortScratch& s, size_t n, int key_bits);      // digit width (8 or 9 bits) of a sort of key_bits-bit keys
 int sort_plan_passes(int key_bits, int rb);                          // ... and the launches it takes
 hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
 // Layout of the SoA shadow (preprocess.hip).  The repack kernel verifies what a compact layout assumes, bit for bit, for every record, and

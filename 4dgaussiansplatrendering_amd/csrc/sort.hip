@@ -643,14 +643,13 @@ static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint3
 
 // Digit width of a sort of `key_bits`-bit keys: 9-bit digits (512 bins) where they save a pass over 8-bit ones — 17-18 and 25-27 key bits, e.g. the
 // depth keys of slowly moving (4D) splats, whose host-proven span is a little wider than 2^24; the tile shape needs a thread per bin.
-int sort_plan_rb(const SortScratch& s, size_t n, int key_bits, bool depth_keys) {
+int sort_plan_rb(const SortScratch& s, size_t n, int key_bits) {
     (void)n;
     if (s.rb_knob == 8 || s.rb_knob == 9) return (s.rb_knob == 9 && (s.shape_knob == 1 || s.shape_knob == 4)) ? 8 : s.rb_knob;      // test hook (the 256-thread shapes have no 512-bin form)
     if (s.shape_knob == 1 || s.shape_knob == 4) return 8;
     const int p8 = std::max(2, (key_bits + 7) / 8), p9 = std::max(2, (key_bits + 8) / 9);
     // (Beyond 27 bits both take four launches.  Preferring 9-bit digits there — their last digit is bits 27-31 only and is skipped on the device when
     // no key reaches 2^27 above the bias — was measured on the 4D sweep of BASELINE.json configs[3], whose bound is open-ended: 39.36 against 39.26 ms, nothing.)
-    (void)depth_keys;
     return p9 < p8 ? 9 : 8;
 }
 int sort_plan_passes(int key_bits, int rb) { return std::min(OS_MAX_PASSES, std::max(2, (key_bits + rb - 1) / rb)); }      // an even number of executed passes always exists (see os_schedule)
@@ -661,7 +660,7 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
     hipError_t e = sort_scratch_reserve(st, s, n);
     if (e != hipSuccess) return e;
     // the producer of the histograms (have_hist) counted digits of s.hist_rb bits: whoever set hist_bits chose it with sort_plan_rb
-    const int rb = have_hist ? s.hist_rb : sort_plan_rb(s, n, key_bits, false);
+    const int rb = have_hist ? s.hist_rb : sort_plan_rb(s, n, key_bits);
     if (rb != 8 && rb != 9) return hipErrorInvalidValue;
     const int passes = sort_plan_passes(key_bits, rb);
     // 8192-key tiles: 1024 threads x 8 keys (streaming stores) for small sorts, 512 x 16 (ordinary stores) beyond 1.5M keys.  Alone, a pass over
