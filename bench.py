@@ -267,15 +267,27 @@ def single_gpu(args, gs4d, scenes, device):
     res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
     tfile = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{'c2' if n == 1_000_000 else 'c3' if n == 10_000_000 else 'x'}.json")
     roofline = roofline_block(res["stats"], res["stage_ms"], res["warm_ms"], n, res["ms_per_step"], tfile)
+    # The four-lane side measurements come first, the one-lane ones last: a context created after a context with another number of frame
+    # lanes runs ~10 % slower (tools/order_effect.py: 0.110 -> 0.122 ms/frame after one one-lane context has been created and closed; HIP maps
+    # the lanes' streams onto its hardware queues differently then) — an artefact of this process's history, not of the workload.
+    n3 = 10_000_000
+    r3 = None
+    if not args.no_c3 and n == 1_000_000:
+        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 5, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
+    one_pair = None
+    if not args.no_latency:
+        # the reference's own buffer layout: ONE key / index pair for every frame (Scenes.h m_key_buf / m_values_buf).  Frame f + 1 writes the
+        # buffers frame f's sort is still filling: the lanes order themselves on the device (events), consecutive frames overlap less.
+        r1, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=args.lanes, keybufs=1)
+        one_pair = {"ms_per_step": round(r1["ms_per_step"], 5), "value": r1["value"], "unit": "splats/s",
+                    "note": "same workload with one key / sort-index buffer pair instead of one per frame lane: the write-after-write dependency between consecutive frames' sorts serialises part of every frame"}
     latency = None
     if not args.no_latency:
         one, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=1, steady_stages=16)
         latency = round(one["ms_per_step"], 5)
         alone_block(roofline, one, n)
     c3 = None
-    if not args.no_c3 and n == 1_000_000:
-        n3 = 10_000_000
-        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 5, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
+    if r3 is not None:
         c3 = {"workload": "10,000,000 random 3D splats in a 400^3 cube, single 1080p frame (BASELINE.json configs[2])", "splats": n3,
               "ms_per_step": r3["ms_per_step"], "value": r3["value"], "unit": "splats/s", "windows_ms_per_step": r3["windows_ms_per_step"],
               "tile_list_entries": r3["stats"]["entries"], "longest_tile_list": r3["stats"]["longest_list"], "unordered_draws": r3["stats"]["unordered_draws"],
@@ -285,13 +297,6 @@ def single_gpu(args, gs4d, scenes, device):
             one3, _, _ = measure_single(gs4d, scenes, n3, 10, 5, 3, device, stage_events=False, lanes=1, steady_stages=8)
             c3["latency_ms_one_lane"] = round(one3["ms_per_step"], 5)
             alone_block(c3["roofline"], one3, n3)
-    one_pair = None
-    if not args.no_latency:
-        # the reference's own buffer layout: ONE key / index pair for every frame (Scenes.h m_key_buf / m_values_buf).  Frame f + 1 writes the
-        # buffers frame f's sort is still filling: the lanes order themselves on the device (events), consecutive frames overlap less.
-        r1, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=args.lanes, keybufs=1)
-        one_pair = {"ms_per_step": round(r1["ms_per_step"], 5), "value": r1["value"], "unit": "splats/s",
-                    "note": "same workload with one key / sort-index buffer pair instead of one per frame lane: the write-after-write dependency between consecutive frames' sorts serialises part of every frame"}
     cpu = None if args.no_cpu_baseline else cpu_baseline(rec, cam, view, proj)
     st = res["stats"]
     return {
