@@ -121,6 +121,9 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     g_rank = rank;
     gs4d_ctx* ctx = nullptr;
     HIPOK(hipSetDevice(local_rank));
+    // The context first, the communicator and this program's own stream after it: the frame lanes' streams are then the first streams the process
+    // creates (streams alive at context creation change how HIP maps the lanes onto hardware queues: tools/order_effect.py).
+    if (gs4d_create(local_rank, a.width, a.height, &ctx) != GS4D_OK) { fprintf(stderr, "[rank %d] gs4d_create: %s\n", rank, gs4d_last_error(nullptr)); return 1; }
     // ---- communicator ----
     Rendezvous rv;
     memset(&rv, 0, sizeof rv);
@@ -154,7 +157,6 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     const size_t n = a.splats;
     std::vector<float> rec;
     make_records(n, rec);
-    if (gs4d_create(local_rank, a.width, a.height, &ctx) != GS4D_OK) { fprintf(stderr, "[rank %d] gs4d_create: %s\n", rank, gs4d_last_error(nullptr)); return 1; }
     GSOK(gs4d_set_stream(ctx, stream));
     uint64_t st[8];
     GSOK(gs4d_get_stats(ctx, st));

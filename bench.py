@@ -321,18 +321,20 @@ def single_gpu(args, gs4d, scenes, device):
 def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
     import torch.distributed as dist
     sharding = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        dist.init_process_group(backend)
     n = args.splats
     cam = scenes.CAM_CUBE
     view = gs4d.look_at(cam[0], cam[1])
     proj = gs4d.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
     pos4, q, scale, life, fade, vel, rgba = scenes.cube_params_4d(n)
     rec = gs4d.build_records_4d(pos4, q, scale, life, fade, vel, rgba)
+    # the context first, the communicator after it: the frame lanes' streams are then the first streams this process creates (streams that are
+    # alive when a context is created change how HIP maps its lanes onto hardware queues: tools/order_effect.py)
     sc = Scene(gs4d, rec, cam, view, proj, local_rank)
     ctx = sc.ctx
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
     # A torch stream of our own becomes torch's current stream AND the context's caller stream: a packed frame is ordered before the
     # gather that sends it, and the next pack into the same slot after the gather that still reads it.  (Not torch's default stream:
     # its handle is NULL, which gs4d_set_stream reads as "no caller stream" — round 1 and early round 2 passed exactly that.)
