@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <new>
 #include <algorithm>
+#include <vector>
 #include <cmath>
 
 using namespace gs4d;
@@ -158,7 +159,7 @@ struct gs4d_ctx {
              int key_mode = 0; uint32_t bias = 0, span = 0xFFFFFFFFu; float view[16] = { 0 }; } po;
     int blend_src = GS4D_SRC_ALPHA, blend_dst = GS4D_ONE_MINUS_SRC_ALPHA;     // glBlendFunc state (Application.cpp:137-138, 150)
     bool defer_order = true;           // GS4D_FUSE_KEYGEN=0 switches the deferral off (test hook)
-    uint64_t stat_fused = 0, stat_renamed = 0, stat_shadow_bytes = 0;
+    uint64_t stat_fused = 0, stat_renamed = 0, stat_shadow_bytes = 0, stat_streams_rejected = 0;
     bool rename_storage = true;        // GS4D_RENAME=0 switches the storage exchange off (test hook)
     int shrink_votes = 0;
     // Two ways to get a tile's list into blend order.  Lists of up to V2_MAX_LIST entries: built unordered, ordered by the wave that
@@ -645,6 +646,55 @@ int alloc_fbs(gs4d_ctx* c, int w, int h) {
 
 } // namespace
 
+namespace {
+// ---- frame-lane streams on hardware queues of their own ----
+// HIP maps streams onto a few hardware queues (four by default) in an order that depends on every stream the process has created so far;
+// two streams on one queue run their kernels one after the other.  Two frame lanes that share a queue do not overlap — measured: 0.110 ->
+// 0.122 ms/frame at 10^6 splats when ONE foreign stream (a communicator's, a framework's) was alive while the context was created, or a
+// context with another number of lanes had existed before (tools/order_effect.py, tools/queue_probe.hip).  So the lanes' streams are chosen
+// by experiment: a candidate stream is accepted if a short kernel on it runs WHILE a spinning kernel occupies each stream accepted so far.
+__global__ void k_lane_probe_spin(unsigned long long ticks, unsigned long long* out) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { }                // bounded: the 100 MHz counter always advances
+    out[0] = wall_clock64();
+}
+__global__ void k_lane_probe_stamp(unsigned long long* out) { out[0] = wall_clock64(); }
+
+// false also when anything fails: the caller then simply keeps the stream
+static bool streams_run_concurrently(hipStream_t a, hipStream_t b, unsigned long long* scratch /* device, 2 words */) {
+    k_lane_probe_spin<<<dim3(1), dim3(1), 0, a>>>(4000ull /* 40 us */, scratch);
+    k_lane_probe_stamp<<<dim3(1), dim3(1), 0, b>>>(scratch + 1);
+    if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+    unsigned long long h[2] = { 0, 0 };
+    if (hipMemcpy(h, scratch, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    return h[1] < h[0];                                     // the stamp was taken before the spin ended
+}
+
+static hipError_t create_lane_streams(gs4d_ctx* c) {
+    hipError_t e;
+    const bool probe = c->nlanes > 1 && !(getenv("GS4D_PROBE_QUEUES") && atoi(getenv("GS4D_PROBE_QUEUES")) == 0);      // test hook: 0 = take the streams as they come
+    unsigned long long* scratch = nullptr;
+    if (probe && hipMalloc(&scratch, 16) != hipSuccess) scratch = nullptr;
+    std::vector<hipStream_t> good, rejected;
+    const int max_tries = 3 * c->nlanes + 4;
+    for (int t = 0; (int)good.size() < c->nlanes && t < max_tries; ++t) {
+        hipStream_t s = nullptr;
+        if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) break;
+        bool ok = true;
+        if (scratch) for (hipStream_t g : good) if (!streams_run_concurrently(g, s, scratch)) { ok = false; break; }
+        (ok ? good : rejected).push_back(s);
+    }
+    while ((int)good.size() < c->nlanes && !rejected.empty()) { good.push_back(rejected.back()); rejected.pop_back(); }      // fewer hardware queues than lanes: lanes will share
+    c->stat_streams_rejected = rejected.size();
+    for (hipStream_t s : rejected) (void)hipStreamDestroy(s);
+    if (scratch) (void)hipFree(scratch);
+    if ((int)good.size() < c->nlanes) { for (hipStream_t s : good) (void)hipStreamDestroy(s); return hipErrorOutOfMemory; }
+    for (int i = 0; i < c->nlanes; ++i) c->lanes[i].s = good[i];
+    return hipSuccess;
+}
+
+} // namespace
+
 extern "C" {
 
 const char* gs4d_version(void) { return "gs4d 0.2 (gfx950)"; }
@@ -671,9 +721,9 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if (const char* ev = getenv("GS4D_RENAME")) c->rename_storage = atoi(ev) != 0;
     if (const char* ev = getenv("GS4D_SLABS")) { const int v = atoi(ev); if (v >= 1 && v <= (int)V2_MAX_SLABS) { c->slabs = 1; while ((int)c->slabs < v) c->slabs *= 2u; } }      // test hook: depth slabs (a power of two)                         // test hook: instance-ordered tile lists for every draw
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
+    if ((e = create_lane_streams(c)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
     for (int i = 0; i < c->nlanes; ++i) {
         Lane& L = c->lanes[i];
-        if ((e = hipStreamCreateWithFlags(&L.s, hipStreamNonBlocking)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
         for (hipEvent_t* ev : { &L.ev_emit, &L.ev_tail }) {
             if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
             if ((e = hipEventRecord(*ev, L.s)) != hipSuccess) return bail(hipfail(c, e, "hipEventRecord"));      // "already happened"
@@ -1365,7 +1415,7 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
     stats[0] = c->stat_entries; stats[1] = lane(c).pair_cap; stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y | (c->stat_shadow_bytes << 32);
-    stats[4] = c->stat_depth_passes; stats[5] = (c->stat_tile_passes & 0xFFFFFFFFull) | (c->stat_renamed << 32); stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
+    stats[4] = (c->stat_depth_passes & 0xFFFFFFFFull) | (c->stat_streams_rejected << 32); stats[5] = (c->stat_tile_passes & 0xFFFFFFFFull) | (c->stat_renamed << 32); stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }
 

@@ -386,6 +386,53 @@ def test_rgba8_pack_any_width_and_alignment(gs4d, monkeypatch, W, H, offset):
     assert np.any(np.all(want == np.array([64, 128, 191, 255]), axis=2)) and np.any(np.any(want != np.array([64, 128, 191, 255]), axis=2))      # clear tiles and drawn ones
 
 
+def test_lane_streams_are_chosen_beside_foreign_streams(gs4d, monkeypatch):
+    """gs4d_create picks the frame lanes' streams by experiment (a candidate is kept only if a kernel on it runs while a spinning kernel
+    occupies each lane chosen so far): with foreign streams alive in the process — which shift HIP's stream-to-hardware-queue mapping so
+    that two lanes would share a queue — the context still gets its lanes, reports how many candidates it discarded, and renders the same
+    frames as a context that took its streams as they came (GS4D_PROBE_QUEUES=0)."""
+    monkeypatch.delenv("GS4D_DRAW_PATH", raising=False)
+    hip = C.CDLL("libamdhip64.so")
+    foreign = []
+    for _ in range(2):
+        s = C.c_void_p()
+        assert hip.hipStreamCreateWithFlags(C.byref(s), 1) == 0      # hipStreamNonBlocking
+        foreign.append(s)
+    W, H, n = 640, 360, 20000
+    pos, q, sc, rgba = scenes.cube_params(n, seed=23)
+    rec = gs4d.build_records_3d(pos, q, sc * 3.0, rgba)
+    cam = scenes.CAM_CUBE
+    view, proj = cam_mats(gs4d, cam, W, H)
+    imgs = []
+    for probe in ("1", "0"):
+        monkeypatch.setenv("GS4D_PROBE_QUEUES", probe)
+        ctx = gs4d.Context(W, H)
+        st = ctx.stats()
+        assert st["lanes"] >= 1 and st["lane_streams_rejected"] >= 0
+        if probe == "0":
+            assert st["lane_streams_rejected"] == 0
+        db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+        ctx.set_clear_color(gs4d.CLEAR_COLOR)
+        ctx.set_mode(gs4d.MODE_4D_SORTED)
+        frames = []
+        for f in range(6):                                         # more frames than lanes: every lane renders
+            ctx.clear()
+            ctx.set_uniforms(time=float(f), min_opacity=0.0, view=view, proj=proj)
+            ctx.keygen(db, float(f), cam[0], kb, ib, n)
+            ctx.sort_pairs(kb, ib, n)
+            ctx.bind(1, ib)
+            ctx.bind(2, db)
+            ctx.draw_instanced(n)
+            frames.append(ctx.read_pixels())
+        ctx.close()
+        imgs.append(frames)
+    monkeypatch.delenv("GS4D_PROBE_QUEUES", raising=False)
+    for a, b in zip(*imgs):
+        assert np.array_equal(a, b)
+    for s in foreign:
+        assert hip.hipStreamDestroy(s) == 0
+
+
 @pytest.mark.parametrize("rename", [1, 0])
 def test_one_key_pair_for_all_frames(gs4d, oracle, monkeypatch, rename):
     """The reference's buffer layout — ONE key buffer and ONE index buffer for every frame (Scenes.h m_key_buf / m_values_buf) — with frames

@@ -35,4 +35,4 @@ elif mode == "alloc":
         assert hip.hipMalloc(C.byref(p), C.c_size_t(33 << 20)) == 0
         assert hip.hipFree(p) == 0
 res, _, _ = bench.measure_single(gs4d, scenes, n, 20, 5, 7, 0, stage_events=False)
-print(f"{mode} x {k}: {res['ms_per_step']:.5f} ms/frame, windows {res['windows_ms_per_step']}")
+print(f"{mode} x {k}: {res['ms_per_step']:.5f} ms/frame, windows {res['windows_ms_per_step']}, candidate streams rejected at context creation: {res['stats']['lane_streams_rejected']}")
