@@ -662,7 +662,7 @@ __global__ void k_lane_probe_stamp(unsigned long long* out) { out[0] = wall_cloc
 
 // false also when anything fails: the caller then simply keeps the stream
 static bool streams_run_concurrently(hipStream_t a, hipStream_t b, unsigned long long* scratch /* device, 2 words */) {
-    k_lane_probe_spin<<<dim3(1), dim3(1), 0, a>>>(4000ull /* 40 us */, scratch);
+    k_lane_probe_spin<<<dim3(1), dim3(1), 0, a>>>(10000ull /* 100 us of the 100 MHz counter: long against a launch, even under a tracing tool */, scratch);
     k_lane_probe_stamp<<<dim3(1), dim3(1), 0, b>>>(scratch + 1);
     if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
     unsigned long long h[2] = { 0, 0 };
