@@ -27,5 +27,22 @@ int main(int argc, char** argv) {
         printf("%d%d%c ", i, j, h[2] < h[1] ? '|' : '-');      // | concurrent, - serialised
     }
     printf("\n");
+    // a fifth stream beside the four: default priority, then the highest — does it get a hardware queue of its own?
+    for (int high = 0; high < 2; ++high) {
+        hipStream_t x;
+        int lo = 0, hi = 0;
+        OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (high) OK(hipStreamCreateWithPriority(&x, hipStreamNonBlocking, hi)); else OK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        k_stamp<<<1, 1, 0, x>>>(d + 4); OK(hipStreamSynchronize(x));
+        printf("  fifth stream (%s priority) against the four, both ways: ", high ? "highest" : "default");
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long h[3];
+            k_spin<<<1, 1, 0, s[i]>>>(20000ull, d); k_stamp<<<1, 1, 0, x>>>(d + 2); OK(hipDeviceSynchronize());
+            OK(hipMemcpy(h, d, 24, hipMemcpyDeviceToHost)); printf("%dx%c ", i, h[2] < h[1] ? '|' : '-');
+            k_spin<<<1, 1, 0, x>>>(20000ull, d); k_stamp<<<1, 1, 0, s[i]>>>(d + 2); OK(hipDeviceSynchronize());
+            OK(hipMemcpy(h, d, 24, hipMemcpyDeviceToHost)); printf("x%d%c ", i, h[2] < h[1] ? '|' : '-');
+        }
+        printf("\n");
+    }
     return 0;
 }
