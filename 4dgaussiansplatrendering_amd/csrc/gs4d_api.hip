@@ -670,6 +670,10 @@ static bool streams_run_concurrently(hipStream_t a, hipStream_t b, unsigned long
     return h[1] < h[0];                                     // the stamp was taken before the spin ended
 }
 
+#ifdef GS4D_TUNING
+static unsigned long long* g_tuning_spin_out() { static unsigned long long* p = nullptr; if (!p && hipMalloc(&p, 16) != hipSuccess) p = nullptr; return p; }
+#endif
+
 static hipError_t create_lane_streams(gs4d_ctx* c) {
     hipError_t e;
     const bool probe = c->nlanes > 1 && !(getenv("GS4D_PROBE_QUEUES") && atoi(getenv("GS4D_PROBE_QUEUES")) == 0);      // test hook: 0 = take the streams as they come
@@ -1418,6 +1422,15 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     stats[4] = (c->stat_depth_passes & 0xFFFFFFFFull) | (c->stat_streams_rejected << 32); stats[5] = (c->stat_tile_passes & 0xFFFFFFFFull) | (c->stat_renamed << 32); stats[6] = (uint64_t)c->nlanes | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }
+
+#ifdef GS4D_TUNING
+// tuning builds only (make TUNING=1; looked up by name by host/gs4d_sweep --fake-comm-us): occupy `stream` for `usec` microseconds with one spinning
+// thread — a stand-in for a communication kernel that holds the stream's hardware queue while it moves data over a slow link
+__attribute__((visibility("default"))) int gs4d_tuning_spin(void* stream, unsigned usec) {
+    k_lane_probe_spin<<<dim3(1), dim3(1), 0, (hipStream_t)stream>>>((unsigned long long)usec * 100ull, g_tuning_spin_out());
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#endif
 
 int gs4d_debug_read_projected(gs4d_ctx* c, float* out16, size_t nrecords) {
     if (!c || !out16) return GS4D_E_INVALID;

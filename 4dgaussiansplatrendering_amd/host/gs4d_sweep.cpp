@@ -26,6 +26,10 @@
 #include "../../include/gs4d.h"
 
 #include <hip/hip_runtime_api.h>
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE
+#endif
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <chrono>
@@ -46,6 +50,9 @@ namespace {
 
 struct Args {
     int gpus = 1, frames = 256, gather_every = 8, sweeps = 3, warmup = 1, width = 1920, height = 1080;
+    int fake_comm_us = 0;        // experiment (needs a TUNING build of libgs4d.so): every gather also occupies the comm stream for this long per frame it sends
+    int comm_priority = -1;      // the comm stream's priority class: 0 default, 1 highest, 2 lowest; -1 = lowest when there is more than one rank, default otherwise
+    int batch_buffers = 2;       // batch buffers used in turn (2..8)
     size_t splats = 1000000;
     float t_max = 50.0f;
     std::string dump;            // directory: rank 0 writes records.bin and frame_####.rgba8 of the verification sweep (tests)
@@ -150,8 +157,17 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     const ncclUniqueId id = rv.id;
     ncclComm_t comm;
     NCCLOK(ncclCommInitRank(&comm, world, id, rank));
+    // HIP keeps a pool of hardware queues per priority class, and a queue executes in order: in the default class the communication stream shares a
+    // queue with one of the frame lanes, and a send that holds it for a millisecond stalls that lane — and, through the host's validation waits, every
+    // lane.  Emulated on one GPU (--fake-comm-us 150: the stream is held 150 us per frame sent, what 8.3 MB take on one xGMI link): 68.6 ms per sweep
+    // in the default class, 53.3 in the highest, 46.5 in the lowest (rendering alone: 38.0; without any traffic the lowest class costs 40.5).
+    const int comm_priority = a.comm_priority >= 0 ? a.comm_priority : (world > 1 ? 2 : 0);
     hipStream_t stream;
-    HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    if (comm_priority) { int least = 0, greatest = 0; HIPOK(hipDeviceGetStreamPriorityRange(&least, &greatest)); HIPOK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, comm_priority == 2 ? least : greatest)); }
+    else HIPOK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    typedef int (*spin_fn)(void*, unsigned);
+    spin_fn fake_spin = a.fake_comm_us ? (spin_fn)dlsym(RTLD_DEFAULT, "gs4d_tuning_spin") : nullptr;
+    if (a.fake_comm_us && !fake_spin) { fprintf(stderr, "--fake-comm-us needs a tuning build of libgs4d.so (make lib TUNING=1)\n"); return 1; }
 
     // ---- scene, resident on the device ----
     const size_t n = a.splats;
@@ -191,10 +207,11 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     const int most = (a.frames + world - 1) / world;                        // presentations per rank and sweep (rank 0 has the most frames)
     const int G = a.gather_every < 1 ? 1 : a.gather_every;
     const size_t fbytes = (size_t)a.width * a.height * 4;
-    // two batch buffers, used alternately (gather b reads buffer b % 2 while the packs of batch b + 1 fill the other one)
-    uint8_t* batch[2] = { nullptr, nullptr }; uint8_t* gathered[2] = { nullptr, nullptr }; double* dmax = nullptr;
-    hipEvent_t ev_free[2]; bool ev_valid[2] = { false, false };               // recorded behind the gather that last read buffer x
-    for (int x = 0; x < 2; ++x) {
+    // NB batch buffers, used in turn (gather b reads buffer b % NB while the packs of the following batches fill the others)
+    const int NB = a.batch_buffers;
+    uint8_t* batch[8] = { nullptr }; uint8_t* gathered[8] = { nullptr }; double* dmax = nullptr;
+    hipEvent_t ev_free[8]; bool ev_valid[8] = { false };                      // recorded behind the gather that last read buffer x
+    for (int x = 0; x < NB; ++x) {
         if (rank == 0) { HIPOK(hipMalloc(&gathered[x], (size_t)world * G * fbytes)); batch[x] = gathered[x]; }      // rank 0 packs straight into its slice of the gathered batch
         else HIPOK(hipMalloc(&batch[x], G * fbytes));
         HIPOK(hipMemset(batch[x], 0, G * fbytes));
@@ -227,7 +244,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         return 0;
     };
     auto gather = [&](int batch_no, int lo, int hi, bool verify) -> int {      // slots [lo, hi) of batch `batch_no`
-        const int x = batch_no & 1;
+        const int x = batch_no % NB;
         const size_t off = (size_t)lo * fbytes, len = (size_t)(hi - lo) * fbytes;
         const int gi = gathers_this_sweep < max_gathers ? gathers_this_sweep : max_gathers - 1;
         HIPOK(hipEventRecord(g0[gi], stream));
@@ -235,6 +252,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         if (rank == 0) { for (int r = 1; r < world; ++r) NCCLOK(ncclRecv(gathered[x] + (size_t)r * G * fbytes + off, len, ncclUint8, r, comm, stream)); }
         else NCCLOK(ncclSend(batch[x] + off, len, ncclUint8, 0, comm, stream));
         NCCLOK(ncclGroupEnd());
+        if (fake_spin && fake_spin((void*)stream, (unsigned)(a.fake_comm_us * (hi - lo))) != 0) return 1;      // stand-in for the time a real send holds the stream
         HIPOK(hipEventRecord(g1[gi], stream));
         ++gathers_this_sweep;
         HIPOK(hipEventRecord(ev_free[x], stream));                            // buffer x may be packed into again behind this
@@ -260,7 +278,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         int presented = 0, slot_lo = 0;
         gathers_this_sweep = 0;
         auto present = [&](int j, int frames_back) -> int {
-            const int x = (presented / G) & 1;
+            const int x = (presented / G) % NB;
             if (j < (int)mine.size()) GSOK(gs4d_read_frame_rgba8_device_after(ctx, frames_back, batch[x] + (size_t)(presented % G) * fbytes, fbytes, ev_valid[x] ? (void*)ev_free[x] : nullptr));
             ++presented;
             const int b = (presented - 1) / G, hi = (presented - 1) % G + 1;
@@ -329,9 +347,9 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         const double med = sorted.empty() ? 0.0 : sorted[sorted.size() / 2];
         printf("{\"program\": \"gs4d_sweep\", \"n_gpus\": %d, \"splats\": %zu, \"frames\": %d, \"width\": %d, \"height\": %d, \"frames_per_gather_per_rank\": %d, \"frame_lanes\": %d, "
                "\"sweeps\": %d, \"ms_per_sweep\": %.4f, \"ms_per_frame\": %.5f, \"splats_per_s\": %.6g, \"frames_crc32\": \"%08x\", \"unordered_draws\": %llu, \"keygen_in_draw\": %llu, "
-               "\"aborted_discarded\": %llu, \"batch_buffers\": 2, \"comm_stream_busy_ms_per_rank\": [",
+               "\"aborted_discarded\": %llu, \"batch_buffers\": %d, \"comm_stream_busy_ms_per_rank\": [",
                world, n, a.frames, a.width, a.height, G, lanes, a.sweeps, med * 1e3, med * 1e3 / a.frames, med > 0 ? (double)n * a.frames / med : 0.0,
-               a.verify ? crc : 0u, (unsigned long long)(st[7] & 0xFFFFFFFFu), (unsigned long long)(st[6] >> 32), (unsigned long long)(st[2] >> 32));
+               a.verify ? crc : 0u, (unsigned long long)(st[7] & 0xFFFFFFFFu), (unsigned long long)(st[6] >> 32), (unsigned long long)(st[2] >> 32), NB);
         for (int r = 0; r < world; ++r) printf("%s%.3f", r ? ", " : "", comm_all[2 * r]);
         printf("], \"comm_stream_tail_ms_per_rank\": [");
         for (int r = 0; r < world; ++r) printf("%s%.3f", r ? ", " : "", comm_all[2 * r + 1]);
@@ -339,7 +357,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         fflush(stdout);
     }
     gs4d_destroy(ctx);
-    for (int x = 0; x < 2; ++x) { if (rank != 0) (void)hipFree(batch[x]); (void)hipFree(gathered[x]); (void)hipEventDestroy(ev_free[x]); }
+    for (int x = 0; x < NB; ++x) { if (rank != 0) (void)hipFree(batch[x]); (void)hipFree(gathered[x]); (void)hipEventDestroy(ev_free[x]); }
     for (int i = 0; i < max_gathers; ++i) { (void)hipEventDestroy(g0[i]); (void)hipEventDestroy(g1[i]); }
     (void)hipFree(dmax);
     (void)hipStreamDestroy(stream);
@@ -454,6 +472,9 @@ int main(int argc, char** argv) {
         else if (k == "--splats") a.splats = (size_t)atoll(val());
         else if (k == "--frames") a.frames = atoi(val());
         else if (k == "--gather-every") a.gather_every = atoi(val());
+        else if (k == "--fake-comm-us") a.fake_comm_us = atoi(val());
+        else if (k == "--comm-priority") a.comm_priority = atoi(val());
+        else if (k == "--batch-buffers") a.batch_buffers = std::min(8, std::max(2, atoi(val())));
         else if (k == "--sweeps") a.sweeps = atoi(val());
         else if (k == "--warmup") a.warmup = atoi(val());
         else if (k == "--width") a.width = atoi(val());

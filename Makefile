@@ -15,6 +15,12 @@ endif
 # keygen/sort and preprocess must round exactly like the CPU expressions they are checked against
 STRICT   := -ffp-contract=off
 
+# the build mode is a prerequisite of every object: switching between `make lib` and `make lib TUNING=1` rebuilds all of them
+FLAGSTAMP := $(CSRC)/.flags.$(if $(TUNING),tuning,release)
+$(FLAGSTAMP):
+	rm -f $(CSRC)/.flags.*
+	touch $@
+
 OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(CSRC)/tilelist.o $(CSRC)/composite2.o $(CSRC)/lines.o $(HOST)/gs4d_host.o
 
 .PHONY: all lib oracle ref refscene refdraw clean demo sweep
@@ -25,18 +31,18 @@ demo: $(DEMO)
 # the multi-GPU sweep (BASELINE.json configs[3]) driven from C++: the C ABI + HIP + RCCL, one process per GPU
 sweep: $(SWEEP)
 $(SWEEP): $(HOST)/gs4d_sweep.cpp include/gs4d.h $(LIB)
-	g++ -O2 -std=c++17 -Wall -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include $(HOST)/gs4d_sweep.cpp -o $@ -L$(PKG) -lgs4d -L$(ROCM)/lib -lrccl -lamdhip64 -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib
+	g++ -O2 -std=c++17 -Wall -D__HIP_PLATFORM_AMD__ -I$(ROCM)/include $(HOST)/gs4d_sweep.cpp -o $@ -L$(PKG) -lgs4d -L$(ROCM)/lib -lrccl -lamdhip64 -ldl -Wl,-rpath,'$$ORIGIN/..' -Wl,-rpath,$(ROCM)/lib
 $(DEMO): $(HOST)/scene_replay.cpp $(HOST)/gs4d_compat.h include/gs4d.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -o $@ $(HOST)/scene_replay.cpp -L$(PKG) -lgs4d -Wl,-rpath,'$$ORIGIN/..'
 lib: $(LIB)
 
-$(CSRC)/sort.o: $(CSRC)/sort.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile
+$(CSRC)/sort.o: $(CSRC)/sort.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile $(FLAGSTAMP)
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
-$(CSRC)/preprocess.o: $(CSRC)/preprocess.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile
+$(CSRC)/preprocess.o: $(CSRC)/preprocess.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile $(FLAGSTAMP)
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
-$(CSRC)/lines.o: $(CSRC)/lines.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile
+$(CSRC)/lines.o: $(CSRC)/lines.hip $(CSRC)/gs4d_internal.h include/gs4d.h Makefile $(FLAGSTAMP)
 	$(HIPCC) $(HIPFLAGS) $(STRICT) -c $< -o $@
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/gs4d_internal.h $(CSRC)/composite_common.h include/gs4d.h Makefile
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/gs4d_internal.h $(CSRC)/composite_common.h include/gs4d.h Makefile $(FLAGSTAMP)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 $(HOST)/gs4d_host.o: $(HOST)/gs4d_host.cpp include/gs4d.h
 	$(HIPCC) -O2 -std=c++17 -fPIC -fvisibility=hidden $(STRICT) -x c++ -c $< -o $@

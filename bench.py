@@ -338,7 +338,10 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
     # A torch stream of our own becomes torch's current stream AND the context's caller stream: a packed frame is ordered before the
     # gather that sends it, and the next pack into the same slot after the gather that still reads it.  (Not torch's default stream:
     # its handle is NULL, which gs4d_set_stream reads as "no caller stream" — round 1 and early round 2 passed exactly that.)
-    comm_stream = torch.cuda.Stream()
+    # ... in the LOWEST priority class when there are peers to send to: HIP keeps a pool of hardware queues per class and a queue executes in order, so
+    # in the default class the stream shares a queue with one frame lane and a millisecond-long send stalls that lane (emulated on one GPU with
+    # gs4d_sweep --fake-comm-us 150: 68.6 ms per sweep in the default class, 53.3 in the highest, 46.5 in the lowest)
+    comm_stream = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[0]) if world > 1 else torch.cuda.Stream()
     torch.cuda.set_stream(comm_stream)
     assert comm_stream.cuda_stream != 0
     ctx.set_stream(comm_stream.cuda_stream)
