@@ -740,7 +740,13 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     for (hipEvent_t* ev : { &c->ev_user, &c->ev_readback }) {
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess) return bail(hipfail(c, e, "hipEventCreate"));
     }
-    { bool ordered = false; if ((e = lds_atomic_order_selftest(c->lanes[0].s, &ordered)) != hipSuccess) return bail(hipfail(c, e, "lds_atomic_order_selftest")); c->atomic_rank = ordered; }
+    {
+        bool ordered = false;
+        hipStream_t ls[MAX_LANES];
+        for (int i = 0; i < c->nlanes; ++i) ls[i] = c->lanes[i].s;
+        if ((e = lds_atomic_order_selftest(ls, c->nlanes, &ordered)) != hipSuccess) return bail(hipfail(c, e, "lds_atomic_order_selftest"));      // on every lane at once: beside other waves on the CUs
+        c->atomic_rank = ordered;
+    }
     const int shape_knob = getenv("GS4D_SORT_SHAPE") ? atoi(getenv("GS4D_SORT_SHAPE")) : 0, rank_knob = getenv("GS4D_SORT_RANK") ? atoi(getenv("GS4D_SORT_RANK")) : 0;
     for (int i = 0; i < c->nlanes; ++i) {
         for (SortScratch* ss : { &c->lanes[i].depth_sort, &c->lanes[i].pair_sort }) { ss->atomic_rank = c->atomic_rank; ss->shape_knob = shape_knob; ss->rank_knob = rank_knob; ss->rb_knob = getenv("GS4D_SORT_RB") ? atoi(getenv("GS4D_SORT_RB")) : 0; }

@@ -52,7 +52,7 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
 uint32_t* sort_hist_slot(hipStream_t st, SortScratch& s, size_t n_hint, hipError_t* e_out);
 int sort_plan_rb(const SortScratch& s, size_t n, int key_bits);      // digit width (8 or 9 bits) of a sort of key_bits-bit keys
 int sort_plan_passes(int key_bits, int rb);                          // ... and the launches it takes
-hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered);
+hipError_t lds_atomic_order_selftest(const hipStream_t* streams, int nstreams, bool* ordered);      // on all the streams at once
 // Layout of the SoA shadow (preprocess.hip).  The repack kernel verifies what a compact layout assumes, bit for bit, for every record, and
 // reports a violation in bbox[15]; the caller then repacks in the next layout down.
 //   SOA_STATIC3D  64 B/record: a static 3D splat in the reference's 4D record — mu_t, the time row and the time column of sig are the same

@@ -514,16 +514,23 @@ __global__ __launch_bounds__(256) void k_lds_order_test(uint32_t* __restrict__ b
     if (errors) atomicAdd(bad, errors);
 }
 
-hipError_t lds_atomic_order_selftest(hipStream_t st, bool* ordered) {
-    uint32_t* d = nullptr; uint32_t h = 1;
-    hipError_t e = hipMalloc(&d, 4);
+// The test runs on every stream given, at the same time (the frame lanes' streams sit on hardware queues of their own): the workgroups of the
+// launches share the CUs, so each wave is ranked beside waves of another kernel instance — the situation the product's kernels are in.
+hipError_t lds_atomic_order_selftest(const hipStream_t* streams, int nstreams, bool* ordered) {
+    *ordered = false;
+    if (nstreams < 1) return hipErrorInvalidValue;
+    if (nstreams > 8) nstreams = 8;
+    uint32_t* d = nullptr; uint32_t h[8] = { 1, 1, 1, 1, 1, 1, 1, 1 };
+    hipError_t e = hipMalloc(&d, 4 * (size_t)nstreams);
     if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(d, 0, 4, st)) == hipSuccess) {
-        k_lds_order_test<<<dim3(512), dim3(256), 0, st>>>(d);
-        if ((e = hipGetLastError()) == hipSuccess && (e = hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, st)) == hipSuccess) e = hipStreamSynchronize(st);
-    }
+    for (int i = 0; i < nstreams && e == hipSuccess; ++i) e = hipMemsetAsync(d + i, 0, 4, streams[i]);
+    for (int i = 0; i < nstreams && e == hipSuccess; ++i) { k_lds_order_test<<<dim3(512), dim3(256), 0, streams[i]>>>(d + i); e = hipGetLastError(); }
+    for (int i = 0; i < nstreams && e == hipSuccess; ++i) e = hipMemcpyAsync(&h[i], d + i, 4, hipMemcpyDeviceToHost, streams[i]);
+    for (int i = 0; i < nstreams; ++i) { const hipError_t e2 = hipStreamSynchronize(streams[i]); if (e == hipSuccess) e = e2; }
     (void)hipFree(d);
-    *ordered = (e == hipSuccess && h == 0);
+    bool ok = e == hipSuccess;
+    for (int i = 0; i < nstreams; ++i) ok = ok && h[i] == 0;
+    *ordered = ok;
     return e;
 }
 
