@@ -23,7 +23,7 @@ $(FLAGSTAMP):
 
 OBJS := $(CSRC)/gs4d_api.o $(CSRC)/sort.o $(CSRC)/preprocess.o $(CSRC)/binning.o $(CSRC)/composite.o $(CSRC)/tilelist.o $(CSRC)/composite2.o $(CSRC)/lines.o $(HOST)/gs4d_host.o
 
-.PHONY: all lib oracle ref refscene refdraw clean demo sweep
+.PHONY: all lib oracle ref refscene refdraw refgl clean demo sweep
 all: lib oracle demo sweep
 DEMO := $(HOST)/scene_replay
 SWEEP := $(HOST)/gs4d_sweep
@@ -58,6 +58,8 @@ refscene: lib
 	$(MAKE) -C oracle refscene
 refdraw: lib
 	$(MAKE) -C oracle refdraw
+refgl:
+	$(MAKE) -C oracle refgl
 
 clean:
 	rm -f $(OBJS) $(LIB) $(DEMO) $(SWEEP)

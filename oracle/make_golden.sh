@@ -10,3 +10,6 @@ mkdir -p "$HERE/../tests/golden"
 # family (8): the reference's Splat4D::Draw / Splat3D::Draw on the CPU (oracle/ref/refdraw_main.cpp); reads the records refgen just wrote
 make -C "$HERE" refdraw REF="$REF"
 "$HERE/_ref/refdraw" "$REF" "$HERE/../tests/golden"
+# the GPU half: the reference's GLSL programs executed by Mesa llvmpipe (oracle/ref/refgl_main.cpp) -> tests/golden/gl_*.npz
+make -C "$HERE" refgl
+python3 "$HERE/make_golden_gl.py"
