@@ -2,13 +2,17 @@
 // (4DSplatRendering/Renderer.cpp:41-215) with the flat-colour programs Shader/Lines/LineVert.GLSL + LineFrag.GLSL
 // (gl_Position = uViewProj * vec4(aPos, 1), fragColor = uColor) and Line2DVert.GLSL (gl_Position = vec4(aPos, 0, 1)).
 //
-// The fixed-function part is specified here (OpenGL 4.4 core, sections 13.5 and 14.5.2; the reference ships no line images, so the
-// pixels are "parity unpinned" — the CPU checker restates the same rule):
+// The fixed-function part is specified here (OpenGL 4.4 core, sections 13.5 and 14.5.2) and checked against the reference's line
+// programs run by Mesa llvmpipe (tests/golden/gl_lines_*.npz, tests/test_gpu_gl.py): of the default scenes' overlays (grid, axes, unit
+// line, a path strip: 97 121 line pixels at 1080p) 52 pixels differ, each a pair of neighbours swapped where a line passes within a
+// sub-pixel step (1/256) of a pixel boundary at a pixel-centre crossing:
 //   * a segment is clipped to the view volume -w <= x, y, z <= w (Liang-Barsky in clip space), divided by w and mapped to window
 //     coordinates  xw = (x_ndc + 1) W/2,  yw = (y_ndc + 1) H/2  (pixel centres at +0.5, row 0 at the bottom);
 //   * non-antialiased rasterisation of width 1 (14.5.2.1, diamond exit) in its common form: an x-major segment (|dx| >= |dy|) yields
 //     one fragment in every pixel column whose centre lies in [min x, max x), in the row the line passes through at that centre; a
-//     y-major one the same with the roles swapped;
+//     y-major one the same with the roles swapped; a line that runs exactly ON a boundary between two rows (the X axis through the
+//     screen centre of the reference's default cameras does) belongs to the lower one — 14.5.2.1 perturbs such end points by
+//     (-eps, -eps^2) — llvmpipe agrees (before this rule 6 942 of those 97 121 pixels differed);
 //   * wide lines (14.5.2.2): w = round(width) >= 1; the segment is shifted by -(w - 1)/2 in the minor direction and every fragment is
 //     replaced by w fragments stacked in the minor direction;
 //   * every fragment is blended  dst = src * src.a + dst * (1 - src.a)  on all four channels (Application.cpp:150-154), depth test off.
@@ -81,7 +85,7 @@ __device__ __forceinline__ bool line_fragment(const LineSeg& g, uint32_t f, int 
     if (!(i < last)) return false;
     const float t = ((i + 0.5f) - ma) / (mb - ma);
     const float minor = (na + t * (nb - na)) - 0.5f * (float)(wpx - 1);
-    const float j = floorf(minor) + (float)k;
+    const float j = (ceilf(minor) - 1.0f) + (float)k;        // ON a pixel boundary: the pixel below / to the left (see the header)
     const float x = xmajor ? i : j, y = xmajor ? j : i;
     if (!(x >= 0.0f && y >= 0.0f && x < (float)W && y < (float)H)) return false;
     px = (int)x; py = (int)y;

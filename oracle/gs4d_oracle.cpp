@@ -23,14 +23,16 @@
 //   * host parameterisation, camera, sort key, .vdata parse, scene generators:
 //       PINNED bit-for-bit by tests/golden/*.bin, generated here from the reference's own
 //       C++ compiled where it lies (oracle/ref/refgen.cpp -> oracle/_ref/refgen).
-//   * radix sort: the restated GLSL kernels are shown equal to stable argsort(uint key)
-//       (tests/test_oracle_sort.py); the reference holds no golden vectors for it.
-//   * GLSL vertex/fragment math and the fixed-function rasteriser/blender:
-//       PARITY UNPINNED — the reference ships no tests, fixtures or golden images for them and
-//       GLSL cannot be executed in this container (no GL context, no offline GLSL compiler).
-//       The restatement follows the shader text operation by operation; rasteriser coverage and
-//       varying interpolation (not source, OpenGL 4.4 spec only) follow the rule written at
-//       gs4do_covered() below, which is also the rule the HIP kernels implement.
+//   * radix sort, GLSL vertex/fragment math, the fixed-function rasteriser/blender, the overlay lines:
+//       PINNED against the reference's own GLSL programs EXECUTED in the build container: oracle/ref/refgl_main.cpp brings up a
+//       headless OpenGL 4.5 core context on the image's Mesa 23.2.1 llvmpipe (swrast_dri.so + libglapi, no X, no EGL) and runs the
+//       reference's shader files unmodified — transform-feedback captures of the three vertex shaders, RGBA32F images of the three
+//       splat programs and the line program under the reference's blend/clear state, the three compute programs under
+//       radix_sort.hpp:258-392's dispatch sequence.  oracle/make_golden_gl.py wrote tests/golden/gl_*.npz (manifest_gl.json);
+//       tests/test_oracle_gl.py holds this file to them: cull identical record for record, quad centre <= 1.5e-4 px, conic 1.2e-7
+//       relative, p(t) bit-equal up to the exp2 lowering of llvmpipe's exp, permutations identical, images within 1e-4 except at
+//       pixels whose centre lies within 1/128 px of a quad edge (the GL snaps vertices to 1/256 px; gs4do_covered() tests in float):
+//       7 of 23 056 touched pixels at 1080p (tests/gl_cases.py states every bar).
 //
 // float32 throughout, operations in the written order; build with -ffp-contract=off so the only
 // fused operations are the explicit fmaf() calls.
@@ -633,7 +635,7 @@ GS4DO_API void gs4do_composite_blend(const gs4do_proj* proj, const uint32_t* ord
 // ---- overlay lines: Renderer::DrawLine / DrawGrid / DrawAxis (Renderer.cpp:41-215), Shader/Lines/LineVert.GLSL:11, Line2DVert.GLSL:11 ----
 // The vertex stage is the shader's (gl_Position = uViewProj * vec4(aPos, 1) resp. vec4(aPos, 0, 1)); clipping, line rasterisation and
 // the blend are fixed-function in the reference: restated from the OpenGL 4.4 core specification (13.5 clipping, 14.5.2.1 / 14.5.2.2
-// line segments and wide lines, 17.3.8 blending) in the form csrc/lines.hip documents.  PARITY UNPINNED: the reference holds no line
+// line segments and wide lines, 17.3.8 blending) in the form csrc/lines.hip documents.  Pinned against the reference's line programs run by llvmpipe (tests/golden/gl_lines_*.npz, test_oracle_gl.py): the reference holds no line
 // images.  Fragments are blended one after another, segment by segment — the order the GL would produce them in.
 static bool clip_t(float num, float den, float& t0, float& t1) {
     if (den == 0.0f) return num >= 0.0f;
@@ -689,7 +691,7 @@ GS4DO_API void gs4do_draw_lines_blend(float* rgba, int W, int H, const float* ve
             const float t = ((i + 0.5f) - ma) / (mb - ma);
             const float minor = (na + t * (nb - na)) - 0.5f * (float)(wpx - 1);
             for (int k = 0; k < wpx; ++k) {
-                const float j = floorf(minor) + (float)k;
+                const float j = (ceilf(minor) - 1.0f) + (float)k;       // a line ON a pixel boundary belongs to the pixel below/left: GL perturbs by (-eps, -eps^2) (14.5.2.1)
                 const float x = xmajor ? i : j, y = xmajor ? j : i;
                 if (!(x >= 0.0f && y >= 0.0f && x < (float)W && y < (float)H)) continue;
                 float* d = rgba + 4 * ((size_t)(int)y * W + (int)x);

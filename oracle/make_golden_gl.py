@@ -165,6 +165,43 @@ def img_fixture(name, kind, rec, t, min_opacity, cam_pos, view, proj, W, H, embe
                      full_crc32=zlib.crc32(res["img"].tobytes()))
 
 
+def gl_lines(W, H, vp, sets):
+    args = ["lines", W, H, os.path.join(TMP, "vp.bin"), os.path.join(TMP, "lines")]
+    np.asarray(vp, np.float32).tofile(os.path.join(TMP, "vp.bin"))
+    for k, (verts, col, width, strip) in enumerate(sets):
+        cp, vp_ = os.path.join(TMP, f"col{k}.bin"), os.path.join(TMP, f"verts{k}.bin")
+        np.asarray(col, np.float32).tofile(cp)
+        np.ascontiguousarray(verts, np.float32).tofile(vp_)
+        args += [cp, width, len(verts), vp_, int(strip)]
+    refgl(*args)
+    return np.fromfile(os.path.join(TMP, "lines.img.f32"), np.float32).reshape(H, W, 4)
+
+
+def lines_fixture(name, cam, W, H, source):
+    """the overlays every 4D scene's Render() starts with (Scenes.h:303-310): DrawGrid(2000, 2000, 200, 200, {1,1,1,0.15}, cam, 1) with its
+    zero-initialised first half (Renderer.cpp:121), DrawAxis(cam, 500, 3) = three 10-unit lines, the unit line (width 5), the path line of
+    LinearMotion (width 5) and a 60-point strip (width 2) — all into one frame"""
+    view, proj = ol.look_at(cam[0], cam[1]), ol.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
+    vp = (proj.reshape(4, 4).T @ view.reshape(4, 4).T).T.reshape(-1).astype(np.float32)                  # Camera::GetViewProjMatrix, column-major P * V
+    sets = [(gl_cases.grid_vertices(2000.0, 2000.0, 200, 200), (1, 1, 1, 0.15), 1.0, 0)]
+    sets += [(np.array([[0, 0, 0], p], np.float32), c, 3.0, 0) for p, c in (([10, 0, 0], (1, 0, 0, 1)), ([0, 10, 0], (0, 1, 0, 1)), ([0, 0, 10], (0, 0, 1, 1)))]
+    sets += [(np.array([[0, 0, 0], [1, 0, 0]], np.float32), (1, 1, 1, 1), 5.0, 0), (np.array([[0, 0, 0], [50, 0, 0]], np.float32), (1, 0, 0, 1), 5.0, 0)]
+    sets += [(np.stack([np.array([20 * np.cos(a), 5.0 + a, 20 * np.sin(a)], np.float32) for a in np.linspace(0, 6.0, 60)]), (1.0, 0.5, 0.1, 0.8), 2.0, 1)]
+    img = gl_lines(W, H, vp, sets)
+    x0, y0, x1, y1, touched = crop_box(img, ol.CLEAR)
+    arrays = {"size": np.array([W, H], np.int32), "vp": vp, "box": np.array([x0, y0, x1, y1], np.int32), "nsets": np.array([len(sets)], np.int32)}
+    # the image is made of few distinct colours: keep it as a palette + 8-bit indices (lossless)
+    crop = img[y0:y1, x0:x1]
+    pal, inv = np.unique(crop.reshape(-1, 4).view(np.uint32), axis=0, return_inverse=True)
+    assert len(pal) <= 65535
+    arrays["palette"] = pal.view(np.float32)
+    arrays["index"] = inv.reshape(crop.shape[:2]).astype(np.uint16 if len(pal) > 255 else np.uint8)
+    for k, (verts, col, width, strip) in enumerate(sets):
+        arrays[f"verts{k}"] = np.ascontiguousarray(verts, np.float32)
+        arrays[f"style{k}"] = np.array(list(col) + [width, strip], np.float32)
+    MAN[name] = dict(save(name, **arrays), kind="lines", source=source, touched_pixels=touched)
+
+
 def main():
     info = json.loads(subprocess.check_output([REFGL, "info"], stderr=subprocess.DEVNULL))
     print("GL:", info)
@@ -234,6 +271,12 @@ def main():
     img_fixture("gl_img_3dfull_640", "3d", verts, 0.0, 0.0, cam0["pos"], v3, p3, W3, H3, False, "splat_draw_3d_in -> verts72 (buffer order)")
     v, p = VP(cam_2d, 320, 180)
     img_fixture("gl_img_2d_320", "2d", g2, 0.0, 0.0, cam_2d[0], v, p, 320, 180, False, "gaussians2d_records (buffer order)")
+
+    # ---- overlay lines (row f3) ------------------------------------------------------------------------------------------------
+    print("lines:")
+    lines_fixture("gl_lines_teapot_1080p", cam_t, 1920, 1080, "LinearMotion's overlays from its camera")
+    lines_fixture("gl_lines_nonlinear_720p", cam_n, 1280, 720, "the same overlays from NonLinearMotion's camera")
+    lines_fixture("gl_lines_2dcam_640", cam_2d, 640, 360, "the same overlays from Gaussians2D/3D's camera")
 
     # ---- family (c): the sort --------------------------------------------------------------------------------------------
     print("sort:")

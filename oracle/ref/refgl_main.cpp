@@ -32,7 +32,7 @@
 //        img16-> <out_prefix>.img.u16  : the same draw into an RGBA16 (unsigned normalised) attachment: a fixed-point framebuffer like the
 //                                        reference's window — source and result of every blend clamped to [0, 1] (OpenGL 4.4, 17.3.8), which a
 //                                        float attachment does not do — with 1.5e-5 steps instead of 1/255
-//   refgl lines <W> <H> <viewproj.bin> <color.bin> <width> <nverts> <verts.bin> <strip:0|1> <out_prefix>
+//   refgl lines <W> <H> <viewproj.bin> <out_prefix> (<color.bin> <width> <nverts> <verts.bin> <strip:0|1>)+    all sets into one frame
 //   refgl sort <n> <keys.bin> <vals.bin> <out_prefix>      -> <out_prefix>.keys.u32 / .vals.u32
 #include <cmath>
 #include <cstdint>
@@ -318,27 +318,32 @@ static int cmd_draw(int argc, char** argv) {
 // uniforms uViewProj / uColor, glLineWidth(thickness)
 // ---------------------------------------------------------------------------------------------------------------------------
 static int cmd_lines(int argc, char** argv) {
-    if (argc != 11) die("lines: W H viewproj.bin color.bin width nverts verts.bin strip out_prefix");
+    if (argc < 11 || (argc - 6) % 5) die("lines: W H viewproj.bin out_prefix (color.bin width nverts verts.bin strip)+");
     int W = atoi(argv[2]), H = atoi(argv[3]);
-    std::vector<uint8_t> vp = slurp(argv[4]), col = slurp(argv[5]);
-    float width = (float)atof(argv[6]); long nv = atol(argv[7]);
-    std::vector<uint8_t> verts = slurp(argv[8]); int strip = atoi(argv[9]); std::string out = argv[10];
-    if (vp.size() != 64 || col.size() != 16 || verts.size() != (size_t)nv * 12) die("lines: bad input sizes");
-    GLuint vao; glGenVertexArrays(1, &vao); glBindVertexArray(vao);
-    GLuint vbo; glGenBuffers(1, &vbo); glBindBuffer(GL_ARRAY_BUFFER, vbo);
-    glBufferData(GL_ARRAY_BUFFER, (GLsizeiptr)verts.size(), verts.data(), GL_DYNAMIC_DRAW);
-    glEnableVertexAttribArray(0); glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 12, nullptr);
-    GLuint prog = link_program({ compile_file(GL_VERTEX_SHADER, "Shader/Lines/LineVert.GLSL"), compile_file(GL_FRAGMENT_SHADER, "Shader/Lines/LineFrag.GLSL") });
-    Target t = make_target(W, H, GL_RGBA32F); (void)t;
+    std::vector<uint8_t> vp = slurp(argv[4]); std::string out = argv[5];
+    if (vp.size() != 64) die("lines: viewproj must be 16 floats");
+    GLuint prog = link_program({ compile_file(GL_VERTEX_SHADER, "Shader/Lines/LineVert.GLSL"), compile_file(GL_FRAGMENT_SHADER, "Shader/Lines/LineFrag.GLSL") });   // Renderer.h:32-34
+    make_target(W, H, GL_RGBA32F);
     frame_state(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA);
-    glUseProgram(prog);
-    glUniformMatrix4fv(uni(prog, "uViewProj"), 1, GL_FALSE, (const float*)vp.data());
-    const float* c = (const float*)col.data(); glUniform4f(uni(prog, "uColor"), c[0], c[1], c[2], c[3]);
-    float range[2] = { 0, 0 }; glGetFloatv(GL_ALIASED_LINE_WIDTH_RANGE, range);
-    glLineWidth(width);
-    GLenum e = glGetError();
-    fprintf(stderr, "refgl lines: width %g (aliased range %g..%g)%s\n", width, range[0], range[1], e ? " -> GL_INVALID_VALUE in a core context, width stays 1" : "");
-    glDrawArrays(strip ? GL_LINE_STRIP : GL_LINES, 0, (GLsizei)nv);
+    for (int a = 6; a + 4 < argc; a += 5) {
+        std::vector<uint8_t> col = slurp(argv[a]);
+        float width = (float)atof(argv[a + 1]); long nv = atol(argv[a + 2]);
+        std::vector<uint8_t> verts = slurp(argv[a + 3]); int strip = atoi(argv[a + 4]);
+        if (col.size() != 16 || verts.size() != (size_t)nv * 12) die("lines: bad input sizes");
+        // Renderer::DrawLine / DrawGrid body, Renderer.cpp:41-73 / 113-160: program, two uniforms, a fresh VBO + VAO, attribute 0 = vec3, width, draw
+        glUseProgram(prog);
+        glUniformMatrix4fv(uni(prog, "uViewProj"), 1, GL_FALSE, (const float*)vp.data());
+        const float* c = (const float*)col.data(); glUniform4f(uni(prog, "uColor"), c[0], c[1], c[2], c[3]);
+        GLuint vbo; glGenBuffers(1, &vbo); glBindBuffer(GL_ARRAY_BUFFER, vbo);
+        glBufferData(GL_ARRAY_BUFFER, (GLsizeiptr)verts.size(), verts.data(), GL_STATIC_DRAW);
+        GLuint vao; glGenVertexArrays(1, &vao); glBindVertexArray(vao);
+        glEnableVertexAttribArray(0); glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 0, nullptr);
+        glLineWidth(width);
+        GLenum e = glGetError();
+        if (e) fprintf(stderr, "refgl lines: glLineWidth(%g) -> 0x%x\n", width, e);
+        glDrawArrays(strip ? GL_LINE_STRIP : GL_LINES, 0, (GLsizei)nv);
+        glDeleteBuffers(1, &vbo);
+    }
     glFinish(); GLCHK("lines");
     std::vector<float> px((size_t)W * H * 4); glPixelStorei(GL_PACK_ALIGNMENT, 1);
     glReadPixels(0, 0, W, H, GL_RGBA, GL_FLOAT, px.data()); GLCHK("read");

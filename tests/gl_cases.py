@@ -193,3 +193,56 @@ def check_image(fix, img, got, what, tol=1e-4):
     assert m["linf_off_edge"] <= 5e-4, f"{what}: off-edge difference {m['linf_off_edge']}"
     assert touched > 100, f"{what}: empty image"
     return m
+
+
+def grid_vertices(width, height, dx, dy):
+    """The vertex array Renderer::DrawGrid builds (Renderer.cpp:113-135), including its zero-initialised first half."""
+    total = (dx + 1) * 2 + (dy + 1) * 2
+    v = [np.zeros((total, 3), np.float32)]
+    sx, sy = -width / 2.0, -height / 2.0
+    for i in range(dx + 1):
+        x = np.float32(sx) + np.float32(width / dx) * np.float32(i)
+        v.append(np.array([[x, 0, sy], [x, 0, -sy]], np.float32))
+    for i in range(dy + 1):
+        z = np.float32(sy) + np.float32(height / dy) * np.float32(i)
+        v.append(np.array([[sx, 0, z], [-sx, 0, z]], np.float32))
+    return np.concatenate(v)
+
+
+def line_sets(fix):
+    for k in range(int(fix["nsets"][0])):
+        st = fix[f"style{k}"]
+        yield fix[f"verts{k}"], tuple(float(x) for x in st[:4]), float(st[4]), bool(st[5])
+
+
+def gl_lines_image(fix):
+    W, H = (int(x) for x in fix["size"])
+    img = np.empty((H, W, 4), np.float32)
+    img[:] = CLEAR
+    x0, y0, x1, y1 = (int(x) for x in fix["box"])
+    img[y0:y1, x0:x1] = fix["palette"][fix["index"].astype(np.int64)]
+    return img
+
+
+def check_lines(fix, img, what):
+    """Overlay lines against the reference's line programs run by llvmpipe.  The rule of csrc/lines.hip reproduces the GL's pixels except
+    where a line passes within a sub-pixel step of a pixel boundary at the pixel-centre crossing that decides its row/column (the GL snaps
+    end points to 1/256 px): there the fragment lands in the neighbouring pixel.  Bars: at most 0.2 % of the line pixels differ, every
+    differing pixel has a differing 8-neighbour (a swapped pair) or lies at a segment end, and the summed colour over the frame agrees
+    (fragments move, none appear or vanish beyond the segment ends)."""
+    ref = gl_lines_image(fix)
+    d = np.abs(img.astype(np.float64) - ref).max(axis=2)
+    line_px = int((np.abs(ref - CLEAR).max(axis=2) > 0).sum())
+    bad = d > 1e-6
+    m = {"line_pixels": line_px, "differing": int(bad.sum()), "linf_elsewhere": float(d[~bad].max())}
+    assert line_px > 1000, f"{what}: no lines in the fixture"
+    assert bad.sum() <= max(8, line_px // 500), f"{what}: {int(bad.sum())} of {line_px} line pixels differ"
+    ys, xs = np.nonzero(bad)
+    H, W = bad.shape
+    lonely = 0
+    for x, y in zip(xs, ys):
+        nb = bad[max(0, y - 1):min(H, y + 2), max(0, x - 1):min(W, x + 2)].sum() - 1
+        lonely += int(nb == 0)
+    m["lonely"] = lonely
+    assert lonely <= 8, f"{what}: {lonely} differing pixels without a differing neighbour"
+    return m

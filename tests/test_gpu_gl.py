@@ -5,6 +5,7 @@ permutation are judged against what the reference's own shaders produced (gl_cas
 
   vertex stage   Splat4DVertexShaderInstanced.GLSL:81-150, Splat3DVertexShaderFull.GLSL:43-98, Splat2DVSI.GLSL:59-94   (transform feedback)
   images         + Splat4DFragShader.GLSL:16-31 / 3D / 2D, the rasteriser, the blend of Application.cpp:150-154            (RGBA32F attachment)
+  lines          Shader/Lines/LineVert.GLSL + LineFrag.GLSL, Renderer.cpp:41-215                                          (RGBA32F attachment)
   sort           radix_sort_{count,local_offsets,reorder}.comp.glsl under radix_sort.hpp:258-392                          (permutation)
 """
 import zlib
@@ -107,6 +108,22 @@ def test_image(gs4d, oracle, draw_path, name):
     ctx.close()
     m = gl.check_image(fix, img, gl.got_from_device(p16), f"{name} [{draw_path}]")
     print(name, draw_path, m)
+
+
+@pytest.mark.parametrize("name", gl.names("gl_lines_"))
+def test_overlay_lines(gs4d, name):
+    """row f3: csrc/lines.hip against Shader/Lines/LineVert.GLSL + LineFrag.GLSL run by the GL (grid, axes, unit line, path, strip)"""
+    fix = gl.load(name)
+    W, H = (int(x) for x in fix["size"])
+    ctx = gs4d.Context(W, H)
+    ctx.set_clear_color(gs4d.CLEAR_COLOR)
+    ctx.clear()
+    for verts, col, width, strip in gl.line_sets(fix):
+        ctx.draw_lines(verts, col, width, viewproj=fix["vp"], strip=strip)
+    img = ctx.read_pixels()
+    ctx.close()
+    m = gl.check_lines(fix, img, name)
+    print(name, m)
 
 
 def test_sort_permutations(gs4d):

@@ -386,7 +386,7 @@ def _grid_vertices(width, height, dx, dy):
 
 def test_overlay_lines_then_splats(gs4d, oracle, monkeypatch):
     """What every 4D scene's Render() starts with (Scenes.h:303-310): grid, axes, a path — then the splats over them.  The line
-    rasterisation rule is the build's (GL leaves it to the implementation; csrc/lines.hip states it): parity unpinned, GPU == checker."""
+    rasterisation rule is csrc/lines.hip's, held to the reference's line programs run by llvmpipe in test_gpu_gl.py::test_overlay_lines; here GPU == checker."""
     W, H = 1280, 720
     ctx = _ctx(gs4d, W, H, monkeypatch)
     cam = scenes.CAM_TEAPOT

@@ -21,7 +21,7 @@ def test_fixture_files_match_manifest():
             raw = open(os.path.join(gl.GOLDEN, name + ".npz"), "rb").read()
             assert len(raw) == ent["bytes"] and zlib.crc32(raw) == ent["crc32"], name
             n += 1
-    assert n == len(gl.names("gl_")) and n >= 30
+    assert n == len(gl.names("gl_")) and n >= 33
 
 
 @pytest.mark.parametrize("name", gl.names("gl_vs_"))
@@ -108,3 +108,15 @@ def test_sort_permutations(oracle):
         key = oracle.golden(f"linear_keys_t{k}_first4000").astype(np.float32)
         _, perm = oracle.sort_pairs(key.view(np.uint32), np.arange(key.size, dtype=np.uint32), "std")
         assert np.array_equal(perm, fix[f"perm_linear_keys_t{k}_first4000"])
+
+
+@pytest.mark.parametrize("name", gl.names("gl_lines_"))
+def test_overlay_lines(oracle, name):
+    """row f3: Renderer::DrawGrid / DrawAxis / DrawLine (Renderer.cpp:41-215) through Shader/Lines/LineVert.GLSL + LineFrag.GLSL"""
+    fix = gl.load(name)
+    W, H = (int(x) for x in fix["size"])
+    img = oracle.clear_image(W, H)
+    for verts, col, width, strip in gl.line_sets(fix):
+        oracle.draw_lines(img, verts, col, width, viewproj=fix["vp"], strip=strip)
+    m = gl.check_lines(fix, img, name)
+    print(name, m)

@@ -1,6 +1,6 @@
 """CPU: properties of the oracle's vertex/fragment/blend restatement that follow from the shader text
-(Splat4DVertexShaderInstanced.GLSL, Splat4DFragShader.GLSL, Application.cpp:150-154).  The reference ships no fixtures
-for this half (parity unpinned, see oracle/gs4d_oracle.cpp header); these tests pin the algebra the shaders imply."""
+(Splat4DVertexShaderInstanced.GLSL, Splat4DFragShader.GLSL, Application.cpp:150-154).  The pin of this half is test_oracle_gl.py (the
+reference's shaders executed by Mesa llvmpipe); these tests state the algebra the shaders imply, case by case."""
 import numpy as np
 
 import scenes
