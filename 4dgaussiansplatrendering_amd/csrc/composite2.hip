@@ -73,7 +73,8 @@ struct WaveSort {
 template <bool PREMULT_C, int PER>
 __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
                                                      const uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, int tiles_x, int W, int H, uint32_t* __restrict__ tstate, uint32_t epoch, float4 clear,
-                                                     float4* __restrict__ fb, int key_passes, int rec_passes, uint32_t slabs) {
+                                                     float4* __restrict__ fb, int key_passes, int rec_passes, uint32_t slabs,
+                                                     const uint4* __restrict__ bstat, uint32_t nb, const uint32_t* __restrict__ sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap) {
     // the sort's key plane and the blend's record staging never live at the same time: one piece of LDS serves both
     constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
     __shared__ __attribute__((aligned(16))) uint32_t sh_a[SHARED_WORDS];
@@ -87,8 +88,31 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     const uint32_t lane = threadIdx.x;
     // what the list kernels found out — entries, longest list, abort flags — goes to the host from here (pinned, mapped memory behind
     // the lane's event): they are complete now, and none of them has to wait for a hand-off of its own
-    if (blockIdx.x == 0u && lane == 0u) { total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = total[4]; total_host[1] = total[1]; }
-    if (total[1] || !real) return;                          // aborted draw (capacity or list length): the host re-runs it
+    // A staged draw (slot_seq != 0, tilelist.hip) has no scan kernel that could have added anything up: its verdict is the abort word and the
+    // per-bucket statistics {entries, longest run, longest list} and per-segment entry counts, reduced here.  An exact draw reports its statistics
+    // the same way (they size the blocks, runs and buckets of the staged draws that follow) beside the totals its scan kernel left.
+    const bool aborted = slot_seq ? total[TL_ABORT_WORD] == slot_seq : total[1] != 0u;
+    if (blockIdx.x == 0u) {
+        unsigned long long sum = 0ull; uint32_t mrun = 0u, mbucket = 0u, mlist = 0u, mseg = 0u;
+        if (bstat) for (uint32_t b = lane; b < nb; b += 64u) { const uint4 v = bstat[b]; sum += v.x; mrun = max(mrun, v.y); mbucket = max(mbucket, v.x); mlist = max(mlist, v.z); }
+        if (sstat) for (uint32_t w = lane; w < rows; w += 64u) mseg = max(mseg, sstat[w]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            sum += __shfl_xor(sum, off, 64); mrun = max(mrun, (uint32_t)__shfl_xor(mrun, off, 64));
+            mbucket = max(mbucket, (uint32_t)__shfl_xor(mbucket, off, 64)); mlist = max(mlist, (uint32_t)__shfl_xor(mlist, off, 64)); mseg = max(mseg, (uint32_t)__shfl_xor(mseg, off, 64));
+        }
+        if (lane == 0u) {
+            total_host[6] = mrun; total_host[7] = mbucket; total_host[8] = mseg;
+            if (slot_seq) {
+                // flags: 4 = a segment, a run or a bucket did not fit what the host guessed (re-run exactly), 2 = a list longer than the compositor was launched for.
+                // (A segment that overflowed wrote no entries: the bucket statistics then count entries that are not there, and the sum is still the true total.)
+                const bool guess_ok = mrun <= rcap && mbucket <= bcap && mseg <= scap;
+                const uint32_t fl = (guess_ok ? 0u : 4u) | ((aborted && guess_ok) ? 2u : 0u);
+                total_host[0] = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum; total_host[2] = (uint32_t)sum; total_host[3] = (uint32_t)(sum >> 32); total_host[5] = mlist; total_host[1] = fl;
+            } else { total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = total[4]; total_host[1] = total[1]; }
+        }
+    }
+    if (aborted || !real) return;                           // aborted draw (capacity or list length): the host re-runs it
     const int tx0 = (int)(tile % (uint32_t)tiles_x) * TILE, ty0 = (int)(tile / (uint32_t)tiles_x) * TILE;
     const int px = tx0 + (int)(lane & 7u), py = ty0 + (int)(lane >> 3);
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
@@ -148,8 +172,8 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
 
 template <bool PREMULT_C>
 static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int W, int H,
-                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs) {
-#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs)
+                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs, const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap) {
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap)
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
@@ -165,7 +189,8 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
 }
 
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
-                               int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs) {
+                               int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs,
+                               const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap) {
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
@@ -174,8 +199,8 @@ hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* 
 #ifdef GS4D_TUNING
     { static const bool nosort = getenv("GS4D_V2_NOSORT") != nullptr; if (nosort) kp = rp = 0; }      // ablation: what the wave-local list sort costs the kernel (the image is then wrong)
 #endif
-    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs)
-                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs);
+    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap)
+                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap);
 }
 
 } // namespace gs4d

@@ -135,9 +135,16 @@ struct TileCount {                               // hist == nullptr: the ordered
     // Fused key generation (the draw executes a gs4d_keygen + gs4d_sort_pairs that were queued just before it): the projection kernel also
     // writes the caller's key and index buffers and accumulates the digit histograms of the depth sort, exactly as k_keygen would
     float* keys_out = nullptr; uint32_t* idx_out = nullptr; uint32_t* ghist = nullptr; int hist_rb = 8; uint32_t span = 0xFFFFFFFFu; uint32_t* err = nullptr;
+    uint32_t* sstat = nullptr;                   // [rows]: entries of every segment (statistics for the host; every counting launch writes them)
+    // Staged lists (tilelist.hip): the projection kernel itself WRITES the entries.  A workgroup counts its segment's entries per bucket, scans
+    // the counts, places the entries bucket by bucket in LDS and writes them out as ONE dense block: stage_out[segment * scap + offs[b][segment] + k],
+    // k < hist[b][segment].  A segment with more than scap entries stores `seq` into *abort_word instead.  null: count only.
+    uint2* stage_out = nullptr; uint32_t scap = 0; uint32_t* offs = nullptr; uint32_t* abort_word = nullptr; uint32_t seq = 0;
 };
 constexpr uint32_t V2_MAX_LIST = 1024;           // longest list the compositor sorts in LDS (beyond ~1000 entries per tile its LDS footprint costs more occupancy than the ordered path's two sort passes cost time).  Longer per-tile lists are cut into depth slabs (below); beyond V2_MAX_SLABS a draw uses the ordered path
 constexpr uint32_t V2_MAX_SLABS = 64;           // a tile's list is kept as `slabs` sub-lists by equal ranges of the blend key: far slab first, each ordered by itself in the compositor (one wave lane holds a sub-list's table entry: <= 64)
+constexpr int STAGE_R = 4;                       // staged lists: records per thread of a segment (kept in registers between the counting and the placing pass): seg <= STAGE_R * SEG_THREADS
+constexpr uint32_t STAGE_MAX_SCAP = 5120;        // ... and entries of a segment block (LDS: 8 bytes each beside the 12 KB the projection kernel has already)
 constexpr int SEG_THREADS = 512;                 // workgroup size of the kernels that walk a segment of records (k_preprocess<.., true>, k_bucket_scatter)
 // list capacities the compositor is instantiated for (64 entries per lane-register): the smallest one >= n
 inline uint32_t v2_list_capacity(uint32_t n) {
@@ -152,7 +159,16 @@ struct TileLists {
     uint32_t* skey = nullptr; size_t skey_cap = 0;
     uint32_t counters = 0;                                    // LDS counters of k_bucket_tiles: (tiles per bucket) * slabs
     uint32_t nb = 0, rows = 0, seg = 0, slabs = 1, slab_shift = 0;   // geometry of the current draw (tile_lists_plan): slab of an entry = min(slabs - 1, key >> slab_shift)
+    // staged lists: segment blocks [rows][scap] entries; per-bucket statistics {entries, longest run, longest list, 0} written by k_bucket_tiles_staged
+    // (staged draws) or k_bucket_scan (exact draws), per-segment entry counts written by the projection kernel; the compositing kernel's first
+    // workgroup reduces both for the host
+    uint2* slot_mem = nullptr; size_t slot_cap = 0;           // in entries
+    uint4* bstat = nullptr;                                    // [nb_cap]
+    uint32_t* sstat = nullptr;                                 // [1024]
+    uint32_t cpr = 0, scap = 0, bcap = 0;                     // of the current draw when it is staged (cpr != 0): 8-entry chunks a (bucket, segment) run may have, entries a segment block holds, bucket capacity in the tile-ordered entry array
+    uint32_t seq = 0;                                          // sequence number of the lane's staged draws: total[TL_ABORT_WORD] == seq <=> this draw was aborted
 };
+constexpr int TL_ABORT_WORD = 9;                              // index into BinScratch::total
 // false: this frame / record count cannot use the unordered path (more than 256 * 1024 tiles, or 2^24 records)
 // key_span: host-proven largest blend key (the slabs divide [0, key_span] evenly)
 bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span = 0xFFFFFFFFu, size_t expect_entries = 0);
@@ -164,8 +180,15 @@ hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uin
 // skey == nullptr: the blend keys the projection left in t.skey; else an array of key bit patterns from which skey_bias is still to be subtracted (the caller's key buffer of a fused draw)
 hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint32_t* trects, const float4* proj, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint);
+// staged draws: the segment blocks the projection kernel wrote (t.slot_mem, t.scap) -> tile lists at entries[b * t.bcap ...]; per-bucket statistics into t.bstat;
+// total[TL_ABORT_WORD] = t.seq when a run, a bucket or a list does not fit
+hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint2* entries, uint32_t hint);
+hipError_t tile_lists_reserve_slots(hipStream_t st, TileLists& t, size_t entries);
+// bstat / nb, sstat / rows: per-bucket and per-segment statistics for the host report; slot_seq != 0: a staged draw (aborted <=> total[TL_ABORT_WORD] == slot_seq,
+// the entry total is the sum of the statistics); rcap / scap / bcap: what the host guessed for it (longest run, fullest segment, fullest bucket)
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
-                               int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs);
+                               int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs,
+                               const uint4* bstat = nullptr, uint32_t nb = 0, const uint32_t* sstat = nullptr, uint32_t rows = 0, uint32_t slot_seq = 0, uint32_t rcap = 0, uint32_t scap = 0, uint32_t bcap = 0);
 
 #ifdef __HIPCC__
 // tiles touched by a pixel rectangle (x0|y0<<16, x1|y1<<16; x0 > x1: none), restricted to the tile rows ty % world == rank

@@ -176,7 +176,7 @@ __device__ __forceinline__ uint2 emit(const PreOut& out, uint32_t i, bool valid,
     // the GL clamps a fragment's colour to [0, 1] before blending into the reference's RGBA8 framebuffer; where the fragment shader passes
     // the colour through unchanged that is a per-record operation (the 3D-Full shader multiplies by c first: clamped per fragment)
     if (clamp_rgb) { r = __saturatef(r); g = __saturatef(g); b = __saturatef(b); }
-    out.trects[i] = pack_trect(rect0, rect1);
+    if (out.trects) out.trects[i] = pack_trect(rect0, rect1);      // (null: nothing downstream reads it — a staged draw writes its list entries itself)
     float4* o = out.proj + (size_t)i * 4;
     // (x components of the two affine rows side by side, likewise y: the compositor forms u and v with packed two-float instructions)
     o[0] = make_float4(cx, cy, a0x, a1x);
@@ -205,6 +205,24 @@ __device__ __forceinline__ void count_buckets(uint32_t* h, uint32_t nbm, uint32_
         rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
         rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
         for (uint32_t j = lane; j < rr.count; j += 64u) atomicAdd(&h[tile_of(rr, j, tiles_x) & nbm], 1u);
+    }
+}
+
+// Staged lists, second pass: the same walk again, every entry placed in the workgroup's LDS block at the position a returning LDS atomic on
+// its bucket's cursor hands out (the cursors start at the scanned counts of the first pass).
+__device__ __forceinline__ void place_buckets(uint32_t* cur, uint32_t nbm, uint32_t nbs, uint32_t tiles_x, const TRect& r, uint32_t key, uint32_t rec, uint2* stage) {
+    const bool big = r.count > 16u;
+    if (!big) for_each_tile(r, tiles_x, [&](uint32_t t) { stage[atomicAdd(&cur[t & nbm], 1u)] = make_uint2(key, ((t >> nbs) << 24) | rec); });
+    uint64_t m = __ballot(big);
+    const uint32_t lane = threadIdx.x & 63u;
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1ull;
+        TRect rr;
+        rr.tx0 = __shfl(r.tx0, src, 64); rr.ty0 = __shfl(r.ty0, src, 64); rr.wx = __shfl(r.wx, src, 64);
+        rr.rows = __shfl(r.rows, src, 64); rr.tstep = __shfl(r.tstep, src, 64); rr.count = __shfl(r.count, src, 64);
+        const uint32_t key2 = __shfl(key, src, 64), rec2 = __shfl(rec, src, 64);
+        for (uint32_t j = lane; j < rr.count; j += 64u) { const uint32_t t = tile_of(rr, j, tiles_x); stage[atomicAdd(&cur[t & nbm], 1u)] = make_uint2(key2, ((t >> nbs) << 24) | rec2); }
     }
 }
 
@@ -383,24 +401,30 @@ __global__ __launch_bounds__(256) void k_preprocess(SRC src, uint32_t n, PU u, P
 // FUSE_KEYS: it is also k_keygen (sort.hip) for these records — the key it derives the blend order from IS the depth key: written to the
 // caller's key buffer with the identity index beside it, bounds-checked, and counted into the depth sort's digit histograms.  Without
 // COUNT that is all it adds to the projection: the ordered path's form (the sort follows, then binning.hip reads the sorted index).
-template <class SRC, bool FUSE_KEYS, bool COUNT>
+template <class SRC, bool FUSE_KEYS, int COUNT>      // COUNT: 0 none (ordered path), 1 count per bucket, 2 count + place + write the segment's entries (staged lists)
 __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t n, PU u, PreOut out, TileCount tc) {
     __shared__ uint32_t h[COUNT ? 1024 : 1];
     __shared__ uint32_t kh[FUSE_KEYS ? OS_MAX_PASSES : 1][OS_MAX_BINS];
+    __shared__ uint32_t ws[SEG_THREADS / 64 + 1];
+    extern __shared__ uint2 stage[];                       // COUNT == 2: tc.scap entries
     if (COUNT) for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) h[b] = 0u;
     if (FUSE_KEYS && threadIdx.x < 256u) os_hist_clear(kh, threadIdx.x);
     __syncthreads();
     const uint32_t i0 = blockIdx.x * tc.seg, i1 = min(n, i0 + tc.seg);
-    for (uint32_t ib = i0; ib < i1; ib += SEG_THREADS) {    // uniform trip count: every lane stays for the wave-wide counting
+    // staged lists: what the placing pass needs of every record this thread projected (seg <= STAGE_R * SEG_THREADS: tile_lists_plan / run_draw)
+    uint32_t s_key[COUNT == 2 ? STAGE_R : 1], s_r0[COUNT == 2 ? STAGE_R : 1], s_r1[COUNT == 2 ? STAGE_R : 1];
+#pragma unroll
+    for (int q = 0; q < (COUNT == 2 ? STAGE_R : 1); ++q) { s_key[q] = 0u; s_r0[q] = 1u; s_r1[q] = 0u; }
+    auto round = [&](uint32_t ib, int it) {                 // one record per thread; every lane stays for the wave-wide counting
         const uint32_t i = ib + threadIdx.x;
         TRect r{ 0u, 0u, 0u, 0u, 1u, 0u };
         uint32_t key = 0u;
         if (i < i1) {
             const uint2 rect = project_record(src, n, i, u, out, tc.ks, key);
             if (COUNT) {
-                if (!FUSE_KEYS) tc.skey[i] = key;                             // fused: k_bucket_scatter takes the key from the caller's key buffer, written just below
-
+                if (!FUSE_KEYS && COUNT == 1) tc.skey[i] = key;               // fused: k_bucket_scatter takes the key from the caller's key buffer, written just below
                 r = tile_rect(rect.x, rect.y, (uint32_t)tc.shard_rank, (uint32_t)tc.shard_world);
+                if (COUNT == 2) { s_key[it] = key; s_r0[it] = rect.x; s_r1[it] = rect.y; }
             }
             if (FUSE_KEYS) {
                 tc.keys_out[i] = __uint_as_float(key + tc.ks.bias);          // the blend key is the depth key's bit pattern relative to the bias
@@ -410,9 +434,54 @@ __global__ __launch_bounds__(SEG_THREADS) void k_project_count(SRC src, uint32_t
         }
         if (FUSE_KEYS) os_hist_add(kh, key, i < i1, OS_MAX_PASSES, tc.hist_rb);
         if (COUNT) count_buckets(h, tc.nb - 1u, (uint32_t)tc.tiles_x, r);
+    };
+    if (COUNT == 2) {
+#pragma unroll
+        for (int it = 0; it < STAGE_R; ++it) { const uint32_t ib = i0 + (uint32_t)it * SEG_THREADS; if (ib >= i1) break; round(ib, it); }      // uniform trip count, registers indexed at compile time
+    } else {
+        for (uint32_t ib = i0; ib < i1; ib += SEG_THREADS) round(ib, 0);    // uniform trip count
     }
     __syncthreads();
-    if (COUNT) for (uint32_t b = threadIdx.x; b < tc.nb; b += SEG_THREADS) tc.hist[(size_t)b * tc.rows + blockIdx.x] = h[b];       // one row per bucket: k_bucket_scan scans along the segments
+    if (COUNT) {
+        // the row of counts (one row per bucket: k_bucket_scan / k_bucket_tiles_staged walk along the segments), the segment's total and — staged —
+        // the exclusive scan of the counts: where each bucket's run starts inside the segment's block.  Thread t looks after buckets 2t, 2t + 1.
+        const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b0 = 2u * tid;
+        const uint32_t c0 = b0 < tc.nb ? h[b0] : 0u, c1 = b0 + 1u < tc.nb ? h[b0 + 1u] : 0u, sum = c0 + c1;
+        uint32_t inc = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
+        if (lane == 63u) ws[w] = inc;
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < SEG_THREADS / 64; ++k) { const uint32_t v = ws[k]; if ((unsigned)k < w) base += v; total += v; }
+        const uint32_t o0 = base + inc - sum, o1 = o0 + c0;
+        if (b0 < tc.nb) tc.hist[(size_t)b0 * tc.rows + blockIdx.x] = c0;
+        if (b0 + 1u < tc.nb) tc.hist[(size_t)(b0 + 1u) * tc.rows + blockIdx.x] = c1;
+        if (tid == 0u) tc.sstat[blockIdx.x] = total;
+        if (COUNT == 2) {
+            if (b0 < tc.nb) { tc.offs[(size_t)b0 * tc.rows + blockIdx.x] = o0; h[b0] = o0; }
+            if (b0 + 1u < tc.nb) { tc.offs[(size_t)(b0 + 1u) * tc.rows + blockIdx.x] = o1; h[b0 + 1u] = o1; }
+            const bool fits = total <= tc.scap;            // uniform (every thread added up the same ws[])
+            if (!fits && tid == 0u) *tc.abort_word = tc.seq;      // the block cannot hold this segment: the draw is re-run with exact lists (every writer stores the same value)
+            __syncthreads();
+            if (fits) {
+                const uint32_t nbs = (uint32_t)__ffs((int)tc.nb) - 1u;
+#pragma unroll
+                for (int q = 0; q < STAGE_R; ++q) {
+                    const uint32_t i = i0 + (uint32_t)q * SEG_THREADS + tid;
+                    if (i0 + (uint32_t)q * SEG_THREADS >= i1) break;          // uniform
+                    const TRect r = i < i1 ? tile_rect(s_r0[q], s_r1[q], (uint32_t)tc.shard_rank, (uint32_t)tc.shard_world) : TRect{ 0u, 0u, 0u, 0u, 1u, 0u };
+                    place_buckets(h, tc.nb - 1u, nbs, (uint32_t)tc.tiles_x, r, s_key[q], i, stage);
+                }
+                __syncthreads();
+                // the block leaves the workgroup in one piece: consecutive threads, consecutive 16-byte pieces
+                uint4* __restrict__ dst = reinterpret_cast<uint4*>(tc.stage_out + (size_t)blockIdx.x * tc.scap);
+                const uint4* src4 = reinterpret_cast<const uint4*>(stage);
+                for (uint32_t k = tid; k < (total + 1u) / 2u; k += SEG_THREADS) dst[k] = src4[k];
+            }
+        }
+    }
     if (FUSE_KEYS && threadIdx.x < 256u) os_hist_flush(kh, tc.ghist, OS_MAX_PASSES, threadIdx.x);
 }
 
@@ -426,13 +495,15 @@ static PU make_pu(const Uniforms& un, int W, int H) {
 template <class SRC>
 static hipError_t launch_pre(hipStream_t st, SRC src, size_t n, const Uniforms& un, int W, int H, PreOut out, const TileCount& tc) {
     if (n == 0) return hipSuccess;
-    if (tc.hist && tc.keys_out) k_project_count<SRC, true, true><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
-    else if (tc.hist) k_project_count<SRC, false, true><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    if (tc.hist && tc.stage_out && tc.keys_out) k_project_count<SRC, true, 2><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), (size_t)tc.scap * 8, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    else if (tc.hist && tc.stage_out) k_project_count<SRC, false, 2><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), (size_t)tc.scap * 8, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    else if (tc.hist && tc.keys_out) k_project_count<SRC, true, 1><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
+    else if (tc.hist) k_project_count<SRC, false, 1><<<dim3((unsigned)((n + tc.seg - 1) / tc.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
     else if (tc.keys_out) {
         // segments sized so that at most 2048 workgroups flush digit histograms (1024 global atomics each)
         TileCount t2 = tc;
         t2.seg = (uint32_t)std::max<size_t>(4096, (((n + 2047) / 2048) + SEG_THREADS - 1) / SEG_THREADS * SEG_THREADS);
-        k_project_count<SRC, true, false><<<dim3((unsigned)((n + t2.seg - 1) / t2.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, t2);
+        k_project_count<SRC, true, 0><<<dim3((unsigned)((n + t2.seg - 1) / t2.seg)), dim3(SEG_THREADS), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, t2);
     }
     else k_preprocess<SRC><<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(src, (uint32_t)n, make_pu(un, W, H), out, tc);
     return hipGetLastError();

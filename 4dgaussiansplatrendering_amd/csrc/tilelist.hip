@@ -19,6 +19,11 @@
 //                           (the verdict travels to the host through the first workgroup of the compositing kernel)
 //   k_composite_v2          (composite2.hip)
 //
+// Staged lists (round 4): once a draw of a scene has reported its fullest segment, longest (bucket, segment) run and fullest bucket, the draws
+// that follow skip the scan and the scatter: k_project_count<.., 2> counts, scans and PLACES its segment's entries in LDS and writes them out as
+// one dense block, k_bucket_tiles_staged reads bucket b's run out of every block.  Capacities are guesses (statistics + margin) that the
+// device checks; a draw that does not fit raises total[TL_ABORT_WORD] and is re-run with the exact kernels above.
+//
 // (A first version counted entries per tile with global atomics in the projection kernel and scattered with returning atomics:
 // 1.4e6 device-scope atomics cost 150 us each way on MI355X — they execute at the memory side, ~9e9/s when scattered.  Hence this.)
 // Which key gives "instance order" is decided on the host (KeySrc, gs4d_internal.h).  Lists longer than the compositor can hold, or
@@ -60,7 +65,7 @@ __device__ __forceinline__ unsigned long long bucket_bases(const uint32_t* btot,
 // whole matrix, load after dependent load, cost 100 us).  The workgroup that finishes last turns the bucket totals into bucket starts and
 // checks the capacity — for the kernels and the host that come after.
 __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict__ hist, uint32_t rows, uint32_t nb, uint32_t* __restrict__ offs, uint32_t* __restrict__ btot,
-                                                     uint32_t* __restrict__ bbase, uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t cap) {
+                                                     uint32_t* __restrict__ bbase, uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, uint32_t cap, uint4* __restrict__ bstat) {
     __shared__ uint32_t s_base[1025];
     __shared__ unsigned long long s_ws[4];
     __shared__ uint32_t s_last;
@@ -70,10 +75,11 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict_
         uint32_t c[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) { const uint32_t w = (uint32_t)j * 64u + lane; c[j] = w < rows ? h[w] : 0u; }      // rows <= 1024 (tile_lists_plan)
-        uint32_t carry = 0;
+        uint32_t carry = 0, mxr = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if ((uint32_t)j * 64u >= rows) break;
+            mxr = max(mxr, c[j]);
             uint32_t inc = c[j];
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
@@ -82,6 +88,10 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict_
             carry += __shfl(inc, 63, 64);
         }
         if (lane == 0) __hip_atomic_store(btot + b, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // what a later draw of this scene needs to size its slotted runs (the compositing kernel's first workgroup reduces these for the host)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mxr = max(mxr, (uint32_t)__shfl_xor(mxr, off, 64));
+        if (lane == 0) bstat[b] = make_uint4(carry, mxr, 0u, 0u);
     }
     // the bucket totals were stored write-through (agent-scope atomic stores) and are read back with agent-scope loads: all that is
     // needed before the arrival counter is that this workgroup's stores have left (s_waitcnt) — no cache write-back, which would push
@@ -225,6 +235,102 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
     // (the entry count, the longest list and the flags reach the host through the compositing kernel that follows: no hand-off here)
 }
 
+// Staged draws: no scan and no scatter kernel ran.  The projection kernel (preprocess.hip, k_project_count<.., 2>) wrote every segment's entries as
+// one dense block, bucket after bucket: bucket b's run of segment w is blocks[w * scap + offs[b][w] + k], k < hist[b][w].  This workgroup reads its
+// bucket's counts and offsets, checks what the host only guessed — at most 8 * cpr entries in a run, bcap entries in the bucket, `hint` in a
+// tile's list — and otherwise does what k_bucket_tiles does.  Chunk q of the bucket is entries [8 (q % cpr), +8) of run q / cpr; a thread
+// keeps the chunks of its ROUNDS rounds in registers between counting and placing.  The tile lists of bucket b go to entries[b * bcap ...].
+// Statistics {entries, longest run, longest list} go to bstat[b]; a bucket that does not fit stores the draw's sequence number into *abort_word
+// (every writer stores the same value).
+template <int ROUNDS>
+__global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles_staged(const uint2* __restrict__ blocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t rows, uint32_t cpr, uint32_t scap,
+                                                                    uint32_t bcap, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift, uint32_t nc, uint32_t* __restrict__ tstart,
+                                                                    uint32_t* __restrict__ tcnt, uint2* __restrict__ entries, uint4* __restrict__ bstat, uint32_t* __restrict__ abort_word, uint32_t seq, uint32_t hint) {
+    extern __shared__ uint32_t cnt[];                      // [nc]
+    __shared__ uint32_t ws[BT_THREADS / 64], wm[BT_THREADS / 64];
+    __shared__ uint32_t rc[1024], ro[1024];                // the bucket's run counts and where each run starts (rows <= 1024: tile_lists_plan)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
+    const uint32_t sl = (uint32_t)__ffs((int)slabs) - 1u;
+    for (uint32_t k = tid; k < nc; k += BT_THREADS) cnt[k] = 0u;
+    // ---- the bucket's counts: total, longest run ----
+    const uint32_t myc = tid < rows ? hist[(size_t)b * rows + tid] : 0u;
+    rc[tid] = myc;
+    ro[tid] = tid < rows ? tid * scap + offs[(size_t)b * rows + tid] : 0u;
+    uint32_t tsum = myc, tmax = myc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { tsum += __shfl_xor(tsum, off, 64); tmax = max(tmax, (uint32_t)__shfl_xor(tmax, off, 64)); }
+    if (lane == 0u) { ws[w] = tsum; wm[w] = tmax; }
+    __syncthreads();
+    uint32_t T = 0, maxrun = 0;
+#pragma unroll
+    for (int k = 0; k < BT_THREADS / 64; ++k) { T += ws[k]; maxrun = max(maxrun, wm[k]); }
+    // (a segment that overflowed its block wrote no entries and raised the abort word itself; its counts are still true)
+    const bool fits = maxrun <= 8u * cpr && T <= bcap;     // uniform
+    if (!fits) {
+        if (tid == 0u) { bstat[b] = make_uint4(T, maxrun, 0u, 0u); *abort_word = seq; }
+        return;
+    }
+    __syncthreads();                                        // (ws / wm are reused below)
+    const uint32_t nchunks = rows * cpr;
+    auto counter_of = [&](const uint2& e) { return min(nc - 1u, ((e.y >> 24) << sl) | min(slabs - 1u, e.x >> slab_shift)); };
+    uint2 e[ROUNDS][8];
+    uint32_t ne[ROUNDS];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const uint32_t q = (uint32_t)r * BT_THREADS + tid;
+        ne[r] = 0u;
+        if (q < nchunks) {
+            const uint32_t run = q / cpr, s0 = (q - run * cpr) << 3;
+            const uint32_t c = rc[run];
+            ne[r] = c > s0 ? min(8u, c - s0) : 0u;
+            const uint2* __restrict__ p = blocks + ro[run] + s0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if ((uint32_t)k < ne[r]) e[r][k] = p[k];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if ((uint32_t)k < ne[r]) atomicAdd(&cnt[counter_of(e[r][k])], 1u);
+    __syncthreads();
+    // exclusive scan of the nc counters, the tile table, the longest sub-list (as k_bucket_tiles)
+    const uint32_t cpt = (nc + BT_THREADS - 1u) / BT_THREADS, q0c = tid * cpt;
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t k = 0; k < cpt; ++k) { const uint32_t q = q0c + k; const uint32_t c = q < nc ? cnt[q] : 0u; sum += c; mx = max(mx, c); }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off, 64));
+    if (lane == 63u) ws[w] = inc;
+    if (lane == 0u) wm[w] = mx;
+    __syncthreads();
+    uint32_t wbase = 0, longest = 0;
+#pragma unroll
+    for (int k = 0; k < BT_THREADS / 64; ++k) { if ((unsigned)k < w) wbase += ws[k]; longest = max(longest, wm[k]); }
+    const uint32_t lo = b * bcap;
+    uint32_t run = lo + wbase + inc - sum;
+    for (uint32_t k = 0; k < cpt; ++k) {
+        const uint32_t q = q0c + k;
+        if (q < nc) {
+            const uint32_t c = cnt[q];
+            cnt[q] = run;
+            const uint32_t tile = (q >> sl) * nb + b;
+            if (tile < ntiles) { tstart[(size_t)tile * slabs + (q & (slabs - 1u))] = run; tcnt[(size_t)tile * slabs + (q & (slabs - 1u))] = c; }
+            run += c;
+        }
+    }
+    if (tid == 0u) { bstat[b] = make_uint4(T, maxrun, longest, 0u); if (longest > hint) *abort_word = seq; }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if ((uint32_t)k < ne[r]) {
+            const uint32_t pos = atomicAdd(&cnt[counter_of(e[r][k])], 1u);
+            entries[pos] = make_uint2(e[r][k].x, e[r][k].y & 0x00FFFFFFu);
+        }
+}
+
 bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span, size_t expect_entries) {
     if (nrecords == 0 || nrecords > V2_MAX_RECORDS) return false;
     // buckets: enough that tile / nb < 256, and about 8192 entries each (k_bucket_tiles reads a bucket of that size once) at ~1.4 entries per
@@ -269,10 +375,13 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
     }
     if (t.tiles_cap < ntiles || t.nb_cap < t.nb || t.slabs_cap < t.slabs) {
         if (t.bbase) { (void)hipStreamSynchronize(st); (void)hipFree(t.bbase); }
-        t.bbase = t.btot = t.tstart = t.tcnt = nullptr;
+        t.bbase = t.btot = t.tstart = t.tcnt = nullptr; t.bstat = nullptr; t.sstat = nullptr;
         const size_t nt = std::max(ntiles, t.tiles_cap), nbc = std::max<size_t>(t.nb, t.nb_cap), sc = std::max<size_t>(std::max<size_t>(t.slabs, t.slabs_cap), 4);
-        if ((e = hipMalloc(&t.bbase, (2 * nbc + 1 + 2 * nt * sc) * 4)) != hipSuccess) return e;     // the tile table holds `slabs` sub-lists per tile
+        if ((e = hipMalloc(&t.bbase, (2 * nbc + 4 + 2 * nt * sc) * 4 + nbc * 16 + 1024 * 4)) != hipSuccess) return e;     // the tile table holds `slabs` sub-lists per tile
         t.btot = t.bbase + nbc + 1; t.tstart = t.btot + nbc; t.tcnt = t.tstart + nt * sc;
+        t.bstat = reinterpret_cast<uint4*>(t.bbase + ((2 * nbc + 1 + 2 * nt * sc + 3) & ~(size_t)3));       // [nbc], 16-byte aligned
+        t.sstat = reinterpret_cast<uint32_t*>(t.bstat + nbc);                                                  // [1024]
+        if ((e = hipMemsetAsync(t.bstat, 0, nbc * 16 + 1024 * 4, st)) != hipSuccess) return e;
         t.tiles_cap = nt; t.nb_cap = nbc; t.slabs_cap = sc;
     }
     if (t.skey_cap < nrecords) {
@@ -284,7 +393,18 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
     return hipSuccess;
 }
 
+hipError_t tile_lists_reserve_slots(hipStream_t st, TileLists& t, size_t entries) {
+    if (t.slot_cap >= entries) return hipSuccess;
+    if (t.slot_mem) { (void)hipStreamSynchronize(st); (void)hipFree(t.slot_mem); }
+    t.slot_mem = nullptr; t.slot_cap = 0;
+    hipError_t e = hipMalloc(&t.slot_mem, entries * 8);
+    if (e != hipSuccess) return e;
+    t.slot_cap = entries;
+    return hipSuccess;
+}
+
 void tile_lists_free(TileLists& t) {
+    if (t.slot_mem) (void)hipFree(t.slot_mem);
     if (t.hist) (void)hipFree(t.hist);
     if (t.bbase) (void)hipFree(t.bbase);
     if (t.skey) (void)hipFree(t.skey);
@@ -292,7 +412,7 @@ void tile_lists_free(TileLists& t) {
 }
 
 hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uint32_t* total_host, size_t cap) {
-    k_bucket_scan<<<dim3((t.nb + 3) / 4), dim3(256), 0, st>>>(t.hist, t.rows, t.nb, t.hist + t.hist_cap, t.btot, t.bbase, total, total_host, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFull));
+    k_bucket_scan<<<dim3((t.nb + 3) / 4), dim3(256), 0, st>>>(t.hist, t.rows, t.nb, t.hist + t.hist_cap, t.btot, t.bbase, total, total_host, (uint32_t)std::min<size_t>(cap, 0xFFFFFFFFull), t.bstat);
     return hipGetLastError();
 }
 
@@ -303,6 +423,21 @@ hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint32_t* t
 
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint) {
     k_bucket_tiles<<<dim3(t.nb), dim3(BT_THREADS), t.counters * 4u, st>>>(tmp, t.bbase, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, t.counters, t.tstart, t.tcnt, entries, total, hint);
+    return hipGetLastError();
+}
+
+hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint2* entries, uint32_t hint) {
+    const uint32_t rounds = (t.rows * t.cpr + BT_THREADS - 1) / BT_THREADS;
+#define GS4D_BTS(R) k_bucket_tiles_staged<R><<<dim3(t.nb), dim3(BT_THREADS), t.counters * 4u, st>>>(t.slot_mem, t.hist, t.hist + t.hist_cap, t.rows, t.cpr, t.scap, t.bcap, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, \
+                                                                                                   t.counters, t.tstart, t.tcnt, entries, t.bstat, total + TL_ABORT_WORD, t.seq, hint)
+    switch (rounds) {
+    case 0: case 1: GS4D_BTS(1); break;
+    case 2: GS4D_BTS(2); break;
+    case 3: GS4D_BTS(3); break;
+    case 4: GS4D_BTS(4); break;
+    default: return hipErrorInvalidValue;                  // run_draw does not stage such a draw
+    }
+#undef GS4D_BTS
     return hipGetLastError();
 }
 

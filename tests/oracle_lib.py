@@ -26,6 +26,8 @@ MODE_4D, MODE_4D_DIRECT, MODE_3D, MODE_2D = 0, 1, 2, 3
 
 
 def build():
+    if os.environ.get("GS4D_ORACLE_SO"):                    # tests/san_driver.py: the AddressSanitizer / UBSan build of the checker
+        return os.environ["GS4D_ORACLE_SO"]
     so = os.path.join(ORACLE_DIR, "libgs4d_oracle.so")
     src = os.path.join(ORACLE_DIR, "gs4d_oracle.cpp")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
