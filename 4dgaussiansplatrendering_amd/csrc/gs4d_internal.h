@@ -40,6 +40,9 @@ struct SortScratch {
     int shape_knob = 0, rank_knob = 0; // test / tuning hooks read at context creation: GS4D_SORT_SHAPE (1..6: tile shape of a pass), GS4D_SORT_RANK (1 = ballot ranking, 2 = LDS-atomic ranking)
     uint32_t* totals = nullptr;                                             // [256] spare words (err word when `err` is not set)
     uint32_t* err = nullptr;                                                // not owned: device word raised when a look-back spin times out
+    // persistent workgroups a pass may launch (occupancy x compute units of THIS scratch's device), per kernel instance: asked of the runtime once per
+    // scratch — a scratch belongs to one context, a context to one device; no process-wide cache (two contexts on two devices, or created on two threads)
+    struct Resident { const void* fn = nullptr; uint32_t groups = 0; } resident[16];
 };
 hipError_t sort_scratch_reserve(hipStream_t st, SortScratch& s, size_t n);
 void sort_scratch_free(SortScratch& s);

@@ -588,13 +588,20 @@ template <int THREADS, int ITEMS, bool ATOMIC_RANK, int RB>
 static hipError_t onesweep(hipStream_t st, SortScratch& s, uint32_t* keys, uint32_t* vals, size_t n, const uint32_t* n_dev, int passes, bool have_hist, bool identity_vals) {
     const uint32_t tile_keys = THREADS * ITEMS;
     const uint32_t tiles = (uint32_t)((n + tile_keys - 1) / tile_keys);
-    // persistent workgroups: as many as the device holds at once (asked of the runtime once per shape)
-    static uint32_t resident = 0;
-    if (!resident) {
-        int per_cu = 0, dev = 0; hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_os_pass<THREADS, ITEMS, ATOMIC_RANK, RB>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) prop.multiProcessorCount = 256;
-        resident = (uint32_t)per_cu * (uint32_t)prop.multiProcessorCount;
+    // persistent workgroups: as many as the device holds at once (asked of the runtime once per scratch and kernel instance: the scratch's context has
+    // made its device current)
+    uint32_t resident = 0;
+    {
+        const void* const fn = reinterpret_cast<const void*>(&k_os_pass<THREADS, ITEMS, ATOMIC_RANK, RB>);
+        SortScratch::Resident* slot = nullptr;
+        for (auto& r : s.resident) { if (r.fn == fn) { resident = r.groups; break; } if (!r.fn && !slot) slot = &r; }
+        if (!resident) {
+            int per_cu = 0, dev = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_os_pass<THREADS, ITEMS, ATOMIC_RANK, RB>, THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            resident = (uint32_t)per_cu * (uint32_t)cus;
+            if (slot) { slot->fn = fn; slot->groups = resident; }
+        }
     }
     const uint32_t grid = std::min(tiles, resident);
     uint32_t* ghist = s.hist + (s.flip ? OS_SLOT_WORDS : 0);

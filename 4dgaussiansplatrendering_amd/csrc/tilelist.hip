@@ -171,7 +171,7 @@ __global__ __launch_bounds__(SEG_THREADS) void k_bucket_scatter(const uint32_t* 
 // A thread keeps up to 8 entries in registers (all loads in flight at once); a bucket of up to 8192 entries is read once, a longer one
 // in rounds of 8192, twice.
 constexpr int BT_THREADS = 1024, BT_ITEMS = 8;
-constexpr uint32_t BT_MAX_COUNTERS = 16384;
+constexpr uint32_t BT_MAX_COUNTERS = 12288;      // 48 KB of dynamic LDS beside at most 8.2 KB of static (k_bucket_tiles_staged): inside the 64 KB a workgroup may have without an attribute; tile_lists_plan sends larger frames to the ordered path
 __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __restrict__ tmp, const uint32_t* __restrict__ bbase, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift, uint32_t nc,
                                                              uint32_t* __restrict__ tstart, uint32_t* __restrict__ tcnt, uint2* __restrict__ entries,
                                                              uint32_t* __restrict__ total, uint32_t hint) {

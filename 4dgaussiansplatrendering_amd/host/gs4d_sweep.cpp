@@ -53,6 +53,7 @@ struct Args {
     int fake_comm_us = 0;        // experiment (needs a TUNING build of libgs4d.so): every gather also occupies the comm stream for this long per frame it sends
     int comm_priority = -1;      // the comm stream's priority class: 0 default, 1 highest, 2 lowest; -1 = lowest when there is more than one rank, default otherwise
     int batch_buffers = 2;       // batch buffers used in turn (2..8)
+    int rank0_pct = -1;          // rank 0 renders this percentage of an equal share of the sweep (it also receives every other rank's frames); -1: the model of deal_default_pct()
     size_t splats = 1000000;
     float t_max = 50.0f;
     std::string dump;            // directory: rank 0 writes records.bin and frame_####.rgba8 of the verification sweep (tests)
@@ -176,7 +177,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     GSOK(gs4d_set_stream(ctx, stream));
     uint64_t st[8];
     GSOK(gs4d_get_stats(ctx, st));
-    const int lanes = (int)(st[6] & 0xFFFFFFFFu);
+    const int lanes = (int)(st[6] & 0xFFFFu);
     gs4d_buf data = 0;
     GSOK(gs4d_buffer_create(ctx, rec.data(), rec.size() * 4, &data));
     std::vector<gs4d_buf> keys(lanes), idx(lanes);
@@ -202,9 +203,23 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
     }
 
     // ---- frames of this rank, batches ----
-    std::vector<int> mine;
-    for (int k = rank; k < a.frames; k += world) mine.push_back(k);
-    const int most = (a.frames + world - 1) / world;                        // presentations per rank and sweep (rank 0 has the most frames)
+    // The deal (sharding.py deal()): pct = 100 -> frame k on rank k mod world.  Otherwise rank 0 — which also receives every other rank's frames:
+    // (world - 1) x ~54 GB/s written into its HBM while it renders, out of the ~3 TB/s its own frames' traffic achieves — renders
+    // round(frames / world * pct / 100) frames, spread evenly over the sweep, and the rest go round-robin to ranks 1..world-1.
+    const int pct = a.rank0_pct >= 0 ? a.rank0_pct : std::max(10, (int)std::lround(100.0 * (1.0 - (world - 1) * 54.0 / 3000.0)));
+    std::vector<std::vector<int>> frames_of(world);
+    if (world <= 1 || pct == 100) { for (int k = 0; k < a.frames; ++k) frames_of[world <= 1 ? 0 : k % world].push_back(k); }
+    else {
+        const long n0 = std::min<long>(a.frames, std::max<long>(0, std::lround((double)a.frames / world * pct / 100.0)));
+        int nxt = 0;
+        for (long k = 0; k < a.frames; ++k) {
+            if ((k + 1) * n0 / a.frames > k * n0 / a.frames) frames_of[0].push_back((int)k);
+            else frames_of[1 + nxt++ % (world - 1)].push_back((int)k);
+        }
+    }
+    const std::vector<int>& mine = frames_of[rank];
+    int most = 0;                                                            // presentations per rank and sweep: the busiest rank's frames
+    for (const auto& f : frames_of) most = std::max(most, (int)f.size());
     const int G = a.gather_every < 1 ? 1 : a.gather_every;
     const size_t fbytes = (size_t)a.width * a.height * 4;
     // NB batch buffers, used in turn (gather b reads buffer b % NB while the packs of the following batches fill the others)
@@ -263,8 +278,9 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
             HIPOK(hipStreamSynchronize(stream));
             for (int r = 0; r < world; ++r)
                 for (int p = lo; p < hi; ++p) {
-                    const int k = r + (batch_no * G + p) * world;            // slot p of rank r's batch holds its frame batch_no * G + p
-                    if (batch_no * G + p >= most || k >= a.frames) continue;
+                    const int pn = batch_no * G + p;                          // slot p of rank r's batch holds its pn-th frame
+                    if (pn >= (int)frames_of[r].size()) continue;
+                    const int k = frames_of[r][pn];
                     const uint8_t* f = host_frames.data() + ((size_t)r * G + p) * fbytes;
                     frame_crc[k] = crc32_update(0u, f, fbytes);
                     char name[64];
@@ -353,7 +369,9 @@ int run_rank(const Args& a, int rank, int world, int local_rank, const std::stri
         for (int r = 0; r < world; ++r) printf("%s%.3f", r ? ", " : "", comm_all[2 * r]);
         printf("], \"comm_stream_tail_ms_per_rank\": [");
         for (int r = 0; r < world; ++r) printf("%s%.3f", r ? ", " : "", comm_all[2 * r + 1]);
-        printf("]}\n");
+        printf("], \"rank0_frames_pct_of_equal_share\": %d, \"frames_per_rank\": [", pct);
+        for (int r = 0; r < world; ++r) printf("%s%zu", r ? ", " : "", frames_of[r].size());
+        printf("], \"gather_format\": \"RGBA8\"}\n");
         fflush(stdout);
     }
     gs4d_destroy(ctx);
@@ -452,7 +470,7 @@ int sweep_tiles(const Args& a, int rank, int world, gs4d_ctx* ctx, ncclComm_t co
         printf("{\"program\": \"gs4d_sweep\", \"mode\": \"shard_tiles\", \"n_gpus\": %d, \"splats\": %zu, \"steps_per_window\": %d, \"width\": %d, \"height\": %d, \"frame_lanes\": %d, "
                "\"windows\": %d, \"ms_per_frame\": %.5f, \"splats_per_s\": %.6g, \"image_crc32\": \"%08x\", \"tile_list_entries_rank0\": %llu, \"unordered_draws\": %llu}\n",
                world, n, a.frames, a.width, a.height, lanes, a.sweeps, med * 1e3 / a.frames, med > 0 ? (double)n * a.frames / med : 0.0, crc,
-               (unsigned long long)st[0], (unsigned long long)(st[7] & 0xFFFFFFFFu));
+               (unsigned long long)(st[0] & 0xFFFFFFFFull), (unsigned long long)(st[7] & 0xFFFFFFFFu));
         fflush(stdout);
     }
     for (int x = 0; x < 2; ++x) { if (rank != 0) (void)hipFree(band[x]); (void)hipFree(image[x]); }
@@ -475,6 +493,7 @@ int main(int argc, char** argv) {
         else if (k == "--fake-comm-us") a.fake_comm_us = atoi(val());
         else if (k == "--comm-priority") a.comm_priority = atoi(val());
         else if (k == "--batch-buffers") a.batch_buffers = std::min(8, std::max(2, atoi(val())));
+        else if (k == "--rank0-frames-pct") a.rank0_pct = std::min(100, std::max(0, atoi(val())));
         else if (k == "--sweeps") a.sweeps = atoi(val());
         else if (k == "--warmup") a.warmup = atoi(val());
         else if (k == "--width") a.width = atoi(val());
@@ -484,7 +503,7 @@ int main(int argc, char** argv) {
         else if (k == "--png-every") a.png_every = atoi(val());
         else if (k == "--no-verify") a.verify = false;
         else if (k == "--shard-tiles") a.shard_tiles = true;
-        else { fprintf(stderr, "usage: gs4d_sweep [--gpus N] [--splats n] [--frames 256] [--gather-every 8] [--sweeps 3] [--warmup 1] [--width W --height H] [--dump dir] [--png prefix [--png-every 32]] [--no-verify] [--shard-tiles]\n"); return 2; }
+        else { fprintf(stderr, "usage: gs4d_sweep [--gpus N] [--splats n] [--frames 256] [--gather-every 8] [--sweeps 3] [--warmup 1] [--width W --height H] [--dump dir] [--png prefix [--png-every 32]] [--no-verify] [--shard-tiles] [--rank0-frames-pct P] [--batch-buffers 2] [--comm-priority 0|1|2]\n"); return 2; }
     }
     if (a.gpus < 1 || a.frames < 1 || a.splats < 1 || a.png_every < 1) { fprintf(stderr, "bad arguments\n"); return 2; }
     const char* er = getenv("RANK"); const char* ew = getenv("WORLD_SIZE");

@@ -142,7 +142,7 @@ int main(int argc, char** argv) {
             };
             uint64_t st[8] = { 0 };
             gs4d::compat::Check(gs4d_get_stats(ctx, st), "gs4d_get_stats");
-            const bool swap_chain = (st[6] & 0xFFFFFFFFu) >= 2;                    // one frame lane (GS4D_LANES=1): no previous image is kept, present the current one
+            const bool swap_chain = (st[6] & 0xFFFFu) >= 2;                    // one frame lane (GS4D_LANES=1): no previous image is kept, present the current one
             for (int f = 0; f < frames; ++f) {                                     // Application.cpp:145-190
                 if (png && !swap_chain && f > 0) present(0, f - 1);                // no swap chain: the finished image goes out before Clear() starts the next one
                 renderer.Clear();

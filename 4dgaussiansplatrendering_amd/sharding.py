@@ -13,8 +13,39 @@ def frame_of(step, rank, world):
     return step * world + rank
 
 
-def frames_for_rank(nframes, rank, world):
-    return list(range(rank, nframes, world))
+def default_rank0_pct(world, link_gbs=54.0, frame_mix_gbs=3000.0):
+    """Rank 0 renders AND receives: world - 1 senders write their RGBA8 frames into its HBM at about `link_gbs` each while they render (8.3 MB per
+    1080p frame, ~6 500 frames/s per sender), out of the ~3 TB/s its own frames' traffic mix achieves — its fair share of the frames
+    is an equal share minus that fraction.  100 at world 1, 98 at 2, 87 at 8."""
+    return max(10, int(round(100.0 * (1.0 - (world - 1) * link_gbs / frame_mix_gbs))))
+
+
+def deal(nframes, world, rank0_pct=100):
+    """owner[k] = rank that renders frame k.  rank0_pct = 100: round-robin, frame k -> rank k mod world.  Otherwise rank 0 renders
+    round(nframes / world * rank0_pct / 100) frames, spread evenly over the sweep, and the other frames go round-robin to ranks 1..world-1."""
+    if world <= 1:
+        return [0] * nframes
+    if rank0_pct == 100:
+        return [k % world for k in range(nframes)]
+    n0 = min(nframes, max(0, int(round(nframes / world * rank0_pct / 100.0))))
+    owner, nxt = [], 0
+    for k in range(nframes):
+        if (k + 1) * n0 // nframes > k * n0 // nframes:
+            owner.append(0)
+        else:
+            owner.append(1 + nxt % (world - 1))
+            nxt += 1
+    return owner
+
+
+def frames_for_rank(nframes, rank, world, rank0_pct=100):
+    return [k for k, r in enumerate(deal(nframes, world, rank0_pct)) if r == rank]
+
+
+def most_frames(nframes, world, rank0_pct=100):
+    """frames of the busiest rank: every rank counts this many presentations per sweep, so that all ranks make the same collective calls"""
+    own = deal(nframes, world, rank0_pct)
+    return max(own.count(r) for r in range(world))
 
 
 def sweep_time(frame, nframes, t_max=50.0):
@@ -44,6 +75,42 @@ def gather_schedule(most, every):
             out.append((p, b, lo, hi))
             lo = 0 if p % every == 0 else hi
     return out
+
+
+def run_sweep(nmine, most, every, pipelined, render, pack, gather):
+    """One rank's sweep: the call sequence bench.py (N > 1) and the gloo tests share.  The rank renders its `nmine` frames; presentation is
+    software-pipelined as a swap chain is — frame j is queued first, then frame j - 1 (the previous image) is packed into slot (p % every) of
+    batch buffer (p // every) & 1 — and the batches travel according to gather_schedule(most, every).  Every rank counts `most` presentations (a
+    rank with fewer frames skips the packs it has no frame for), so all ranks make the same collective calls whatever the deal.
+      render(j)                          queue this rank's j-th frame
+      pack(j, frames_back, x, slot)      pack this rank's j-th frame (the image `frames_back` frames behind the current one) into batch x, slot
+      gather(x, lo, hi, first)           slots [lo, hi) of batch x travel; slot lo holds presentation number `first` (this rank's first-th frame)
+    Returns the list of gather calls made (for tests)."""
+    schedule = {p: (b, lo, hi) for p, b, lo, hi in gather_schedule(most, every)}
+    calls, presented = [], 0
+
+    def present(j, frames_back):
+        nonlocal presented
+        x = (presented // every) & 1
+        if j < nmine:
+            pack(j, frames_back, x, presented % every)
+        presented += 1
+        if presented in schedule:
+            _b, lo, hi = schedule[presented]
+            gather(x, lo, hi, presented - (hi - lo))
+            calls.append((presented, x, lo, hi))
+
+    for j in range(most):
+        rendered = j < nmine
+        if rendered:
+            render(j)
+        if not pipelined:
+            present(j, 0)
+        elif j >= 1:
+            present(j - 1, 1 if rendered else 0)          # no new frame was started: frame j - 1 is still the current image
+    if pipelined and most >= 1:
+        present(most - 1, 0)                              # the last frame of the sweep is presented inside the sweep
+    return calls
 
 
 # ---- single-frame sharding by tile rows -----------------------------------------------------------------------------------------

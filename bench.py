@@ -6,10 +6,12 @@ A "step" is one pass of the hot path over splat records already resident in HBM:
 exactly the call sequence of the reference's Scene::Render with sorting on (Scenes.h:312-339), through the C ABI.
 
   N = 1   workload = BASELINE.json configs[1]: 1,000,000 random 3D splats in a 400^3 cube, one 1080p frame per step.  The same
-          invocation also times configs[2] (10^7 splats, the HBM-scale config) into the "c3" block of the line, and the frame time
-          with a single frame lane (nothing overlaps: "latency_ms_one_lane").
+          invocation also times configs[2] (10^7 splats, the HBM-scale config) into the "c3" block of the line, the 10^6 TRUE 4D splats of
+          configs[3] at mid-sweep on this one GPU into "c4_n1" (96-byte records, moving keys), and the frame time with a single frame lane
+          (nothing overlaps: "latency_ms_one_lane").
   N > 1   workload = BASELINE.json configs[3], exactly: 1,000,000 4D splats, the 256-frame time sweep t_k = 50 k / 255, frame k on rank
-          k mod N (one process per GPU, no data-path collective); the finished frames travel to rank 0 in the presentation format
+          k mod N — or, with --rank0-frames-pct below 100, fewer frames on rank 0, which also receives everybody's (one process per GPU, no
+          data-path collective); the finished frames travel to rank 0 in the presentation format
           (RGBA8) with one RCCL gather per --gather-every frames of every rank, from two batch buffers used alternately (a pack never waits
           for the gather that is in flight).  A step is one whole sweep (256 frames), so the total work per step is fixed as N grows:
           "scaling": "strong".  The line carries, per rank, how long the comm stream was busy per sweep and how long it ran on after the
@@ -36,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 W, H = 1920, 1080
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6.3 TB/s
 SWEEP_FRAMES = 256          # BASELINE.json configs[3]
-PROFILE_TAG = "r03"         # profiles/<tag>_pmc_traffic_c{2,3}.json hold the per-launch HBM traffic of this build's kernels
+PROFILE_TAG = "r04"         # profiles/<tag>_pmc_traffic_c{2,3}.json hold the per-launch HBM traffic of this build's kernels
 
 # stage -> (kernel the stage is made of, launches per frame); "sort" and "pairsort" launch counts come from the library's stats
 KERNELS = {"keygen": "gs4d::k_keygen", "sort": "gs4d::k_os_pass", "preprocess": "gs4d::k_project_count", "binning": "gs4d::k_bucket_scatter",
@@ -116,18 +118,36 @@ def timed_windows(step, fence, steps, warmup, windows, reduce_max=None):
     return out
 
 
-def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file):
-    """Dominant credited kernel, priced per launch: achieved = algorithmic bytes per launch / average launch duration from HIP events on the
-    stream the kernel is launched on (gs4d_set_profiling / gs4d_get_timings); traffic = HBM bytes per launch from the rocprofv3 --pmc passes
-    of this command committed under profiles/ (tools/profile_round.sh, tools/pmc_traffic.py)."""
+def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file, one=None):
+    """The dominant credited kernel, priced per launch: achieved = algorithmic bytes per launch / average launch duration from HIP
+    events on the stream the kernel is launched on (gs4d_set_profiling / gs4d_get_timings).
+
+    one = the one-lane run of the same workload in this invocation (every stage timed, nothing overlapping): the block then names the kernel that
+    takes the largest share of the frame's kernel time ALONE and prices it by that duration — `achieved` / `frac` say how well THAT KERNEL uses the
+    memory system.  With four frame lanes in flight the same launch runs beside the other lanes' kernels and lasts 1.5-4x as long; that reading goes
+    into `overlapped` (its frac is a statement about sharing the device, not about the kernel), and `frame` is the throughput evidence: all
+    algorithmic bytes of a frame over the pipelined time per frame.  `moved`: the same kernel priced on the HBM bytes it actually moves (rocprofv3
+    --pmc passes of this command, profiles/<tag>_pmc_traffic_*.json; tools/pmc_traffic.py) — below the algorithmic figure wherever a compact
+    record shadow or a fused producer saves traffic, above it where sectors are fetched for less than they hold."""
     alg = algorithmic_bytes(n, W, H)
-    timed = {k: v for k, v in stage_ms.items() if v > 0 and alg[k] > 0}
-    if not timed:
+    ordered = gs4d_stats["tile_sort_passes"] > 0
+    names = KERNELS_ORDERED if ordered else KERNELS
+    launches_of = lambda st: {"sort": gs4d_stats["depth_sort_passes"], "pairsort": max(1, gs4d_stats["tile_sort_passes"])}.get(st, 1)
+    over = {k: v for k, v in stage_ms.items() if v > 0 and alg[k] > 0}
+    warm = {k: v for k, v in warm_ms.items() if v > 0}
+    alone = {k: v for k, v in (one["steady_ms"] if one and one.get("steady_ms") else {}).items() if v > 0}
+    alone_cred = {k: v for k, v in alone.items() if alg[k] > 0}
+    if alone_cred:
+        credited, basis = max(alone_cred, key=alone_cred.get), "alone"
+        ms = alone_cred[credited]
+    elif over:
+        credited, basis = max(over, key=over.get), "overlapped"
+        ms = over[credited]
+    else:
         return None
-    credited = max(timed, key=timed.get)
-    launches = {"sort": gs4d_stats["depth_sort_passes"], "pairsort": max(1, gs4d_stats["tile_sort_passes"])}.get(credited, 1)
-    kname = (KERNELS_ORDERED if gs4d_stats["tile_sort_passes"] > 0 else KERNELS)[credited]
-    ach = alg[credited] / (timed[credited] * 1e-3) / 1e9
+    launches = launches_of(credited)
+    kname = names[credited]
+    ach = alg[credited] / (ms * 1e-3) / 1e9
     frame_ach = alg["frame"] / (ms_per_step * 1e-3) / 1e9
     traffic, tsrc = None, None
     if os.path.isfile(traffic_file):
@@ -135,41 +155,48 @@ def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file):
         hit = [v for k, v in pm.items() if k.startswith(kname)]
         if hit:
             traffic, tsrc = hit[0]["hbm_bytes_per_launch"], os.path.relpath(traffic_file, ROOT)
-    warm = {k: v for k, v in warm_ms.items() if v > 0}
-    return {"bound": "hbm", "kernel": kname.rstrip("<"), "stage": credited, "launches_per_frame": launches,
-            "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-            "traffic": traffic, "traffic_source": tsrc,
-            "kernel_ms": round(timed[credited] / launches, 5), "algorithmic_bytes_per_launch": alg[credited] // launches,
-            "note": "consecutive frames overlap on the device (frame lanes, one HIP stream each): a launch timed here runs beside the other lane's kernels and is longer than the same launch alone (profiles/README.md lists both)",
-            "slowest_stage": max(warm, key=warm.get) if warm else None,
-            "frame": {"achieved": round(frame_ach, 2), "frac": round(frame_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": alg["frame"]},
-            "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
+    out = {"bound": "hbm", "kernel": kname.rstrip("<"), "stage": credited, "launches_per_frame": launches, "basis": basis,
+           "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+           "traffic": traffic, "traffic_source": tsrc,
+           "kernel_ms": round(ms / launches, 5), "algorithmic_bytes_per_launch": alg[credited] // launches,
+           "frame": {"achieved": round(frame_ach, 2), "frac": round(frame_ach / HBM_PEAK_GBS, 5), "algorithmic_bytes": alg["frame"], "ms_per_frame_pipelined": round(ms_per_step, 5)},
+           "stage_ms_warmup_all_stages_timed": {k: round(v, 5) for k, v in warm_ms.items()}}
+    if traffic:
+        mv = traffic * launches / (ms * 1e-3) / 1e9
+        out["moved"] = {"hbm_bytes_per_launch": traffic, "achieved": round(mv, 2), "frac": round(mv / HBM_PEAK_GBS, 5), "moved_over_algorithmic": round(traffic * launches / alg[credited], 3)}
+    if basis == "alone":
+        tot = sum(alone.values())
+        out["share_of_frame_kernel_time_alone"] = round(ms / tot, 4) if tot > 0 else None
+        out["stage_ms_one_lane"] = {k: round(v, 5) for k, v in (one["steady_ms"] or {}).items()}
+        out["note"] = "kernel, duration and frac: the launch alone (one frame lane, HIP events around every stage, same invocation); `overlapped`: the same launch beside the other lanes' kernels in the pipelined timed windows; `frame`: all algorithmic bytes of a frame over the pipelined time per frame"
+        o_ms = over.get(credited, warm.get(credited))
+        if o_ms:
+            o_ach = alg[credited] / (o_ms * 1e-3) / 1e9
+            out["overlapped"] = {"kernel_ms": round(o_ms / launches, 5), "achieved": round(o_ach, 2), "frac": round(o_ach / HBM_PEAK_GBS, 5),
+                                 "source": "timed windows" if credited in over else "warm-up frames", "slowest_stage": max(warm, key=warm.get) if warm else None}
+    else:
+        out["note"] = "no one-lane run in this invocation: duration and frac are those of a launch that runs beside the other frame lanes' kernels"
+        out["slowest_stage"] = max(warm, key=warm.get) if warm else None
+    return out
 
 
-def alone_block(roofline, one, n):
-    """The credited kernel with nothing beside it: the same HIP-event timing taken in the one-lane run (frames do not overlap there)."""
-    if not roofline:
-        return
-    stage, launches = roofline["stage"], roofline["launches_per_frame"]
-    ms = one["steady_ms"].get(stage, -1.0)
-    if ms <= 0:
-        return
-    ach = algorithmic_bytes(n, W, H)[stage] / (ms * 1e-3) / 1e9
-    roofline["alone"] = {"kernel_ms": round(ms / launches, 5), "achieved": round(ach, 2), "frac": round(ach / HBM_PEAK_GBS, 5),
-                         "note": "same kernel, same events, one frame lane: no other kernel runs beside it",
-                         "stage_ms_one_lane": {k: round(v, 5) for k, v in one["steady_ms"].items()}}
-
-
-def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None, keybufs=4, steady_stages=0):
-    """One GPU, static 3D splats in the cube (configs[1] / configs[2]).  Returns (result dict, records)."""
+def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None, keybufs=4, steady_stages=0, four_d=False, t=0.0):
+    """One GPU: static 3D splats in the cube (configs[1] / configs[2]) or, four_d, the true 4D splats of configs[3] at time t.
+    Returns (result dict, records, camera)."""
     cam = scenes.CAM_CUBE
     view = gs4d.look_at(cam[0], cam[1])
     proj = gs4d.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
-    pos, q, scale, rgba = scenes.cube_params(n)
-    rec = gs4d.build_records_3d(pos, q, scale, rgba)
-    del pos, q, scale, rgba
+    if four_d:
+        pos4, q, scale, life, fade, vel, rgba = scenes.cube_params_4d(n)
+        rec = gs4d.build_records_4d(pos4, q, scale, life, fade, vel, rgba)
+        del pos4, q, scale, life, fade, vel, rgba
+    else:
+        pos, q, scale, rgba = scenes.cube_params(n)
+        rec = gs4d.build_records_3d(pos, q, scale, rgba)
+        del pos, q, scale, rgba
     sc = Scene(gs4d, rec, cam, view, proj, device, lanes=lanes, keybufs=keybufs)
     ctx = sc.ctx
+    frame = (lambda: sc.frame(t))
 
     def fence():
         ctx.finish()
@@ -183,7 +210,7 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
         if k == learn:
             fence()
             ctx.set_profiling(True)
-        sc.frame()
+        frame()
     fence()
     warm_ms = ctx.timings()
     alg = algorithmic_bytes(n, W, H)
@@ -193,9 +220,11 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
     # Frames that aborted on the device (tile-list capacity, list length) and were cleared away before anything observed them are never
     # re-run: a timed window that contains one has timed an incomplete render.  The library counts them; the bench refuses such windows —
     # once more from the start (the context has learned from the aborted frames by then), and if they still contain one, not at all.
+    attempts = 0
     for attempt in range(2):
+        attempts += 1
         aborted_before = ctx.stats()["aborted_discarded"]
-        secs = timed_windows(lambda k: sc.frame(), fence, steps, 0, windows)
+        secs = timed_windows(lambda k: frame(), fence, steps, 0, windows)
         aborted = ctx.stats()["aborted_discarded"] - aborted_before
         if not aborted:
             break
@@ -210,7 +239,7 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
         # while it learned the list capacities of this scene: their stage averages are not a kernel's duration)
         ctx.set_profiling(True)
         for k in range(steady_stages):
-            sc.frame()
+            frame()
         fence()
         steady_ms = ctx.timings()
         ctx.set_profiling(False)
@@ -218,7 +247,7 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
     sc.close()
     ms = sorted(1e3 * s / steps for s in secs)
     med = ms[len(ms) // 2]
-    res = {"ms_per_step": med, "value": n / (med * 1e-3), "windows_ms_per_step": [round(1e3 * s / steps, 5) for s in secs], "aborted_in_timed_windows": aborted,
+    res = {"ms_per_step": med, "value": n / (med * 1e-3), "windows_ms_per_step": [round(1e3 * s / steps, 5) for s in secs], "aborted_in_timed_windows": aborted, "timed_window_attempts": attempts,
            "stats": stats, "warm_ms": warm_ms, "stage_ms": stage_ms, "steady_ms": steady_ms}
     return res, rec, (cam, view, proj)
 
@@ -231,6 +260,7 @@ def main():
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the line reports the median window")
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--gather-every", type=int, default=8, help="N>1: frames of every rank per RCCL gather")
+    ap.add_argument("--rank0-frames-pct", type=int, default=None, help="N>1: rank 0 renders this percentage of an equal share of the sweep (it also receives every other rank's frames); default: sharding.default_rank0_pct(N)")
     ap.add_argument("--lanes", type=int, default=None, help="frame lanes of the context (default: the library's, 4); experiments")
     ap.add_argument("--keybufs", type=int, default=None, help="key / sort-index buffer pairs the application cycles through (default: one per lane)")
     ap.add_argument("--no-c3", action="store_true", help="N=1: skip the configs[2] block (10^7 splats)")
@@ -265,38 +295,43 @@ def single_gpu(args, gs4d, scenes, device):
     n = args.splats
     kb = args.keybufs or args.lanes or 4          # one pair per frame lane (the library default is 4 lanes)
     res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
-    tfile = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{'c2' if n == 1_000_000 else 'c3' if n == 10_000_000 else 'x'}.json")
-    roofline = roofline_block(res["stats"], res["stage_ms"], res["warm_ms"], n, res["ms_per_step"], tfile)
+    tag = "c2" if n == 1_000_000 else "c3" if n == 10_000_000 else "x"
+    tfile = lambda t: os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{t}.json")
     # The four-lane side measurements come first, the one-lane ones last: a context created after a context with another number of frame
     # lanes runs ~10 % slower (tools/order_effect.py: 0.110 -> 0.122 ms/frame after one one-lane context has been created and closed; HIP maps
     # the lanes' streams onto its hardware queues differently then) — an artefact of this process's history, not of the workload.
     n3 = 10_000_000
-    r3 = None
-    if not args.no_c3 and n == 1_000_000:
+    side = not args.no_c3 and n == 1_000_000
+    r3 = r4 = None
+    if side:
         r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 5, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
+        # configs[3]'s workload on ONE GPU: 10^6 true 4D splats (96-byte records: nothing of sig is constant or symmetric-by-construction here), t mid-sweep
+        r4, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 100), 10, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb, four_d=True, t=25.0)
     one_pair = None
     if not args.no_latency:
         # the reference's own buffer layout: ONE key / index pair for every frame (Scenes.h m_key_buf / m_values_buf).  Frame f + 1 writes the
         # buffers frame f's sort is still filling: the lanes order themselves on the device (events), consecutive frames overlap less.
         r1, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=args.lanes, keybufs=1)
         one_pair = {"ms_per_step": round(r1["ms_per_step"], 5), "value": r1["value"], "unit": "splats/s",
-                    "note": "same workload with one key / sort-index buffer pair instead of one per frame lane: the write-after-write dependency between consecutive frames' sorts serialises part of every frame"}
-    latency = None
+                    "note": "same workload with one key / sort-index buffer pair instead of one per frame lane (the reference's layout, Scenes.h:241-247): the drop-in figure"}
+    one = one3 = one4 = None
     if not args.no_latency:
         one, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=1, steady_stages=16)
-        latency = round(one["ms_per_step"], 5)
-        alone_block(roofline, one, n)
-    c3 = None
-    if r3 is not None:
-        c3 = {"workload": "10,000,000 random 3D splats in a 400^3 cube, single 1080p frame (BASELINE.json configs[2])", "splats": n3,
-              "ms_per_step": r3["ms_per_step"], "value": r3["value"], "unit": "splats/s", "windows_ms_per_step": r3["windows_ms_per_step"],
-              "tile_list_entries": r3["stats"]["entries"], "longest_tile_list": r3["stats"]["longest_list"], "unordered_draws": r3["stats"]["unordered_draws"],
-              "aborted_frames_in_timed_windows": r3["aborted_in_timed_windows"],
-              "roofline": roofline_block(r3["stats"], r3["stage_ms"], r3["warm_ms"], n3, r3["ms_per_step"], os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_c3.json"))}
-        if not args.no_latency:
+        if side:
             one3, _, _ = measure_single(gs4d, scenes, n3, 10, 5, 3, device, stage_events=False, lanes=1, steady_stages=8)
-            c3["latency_ms_one_lane"] = round(one3["ms_per_step"], 5)
-            alone_block(c3["roofline"], one3, n3)
+            one4, _, _ = measure_single(gs4d, scenes, n, 30, 10, 3, device, stage_events=False, lanes=1, steady_stages=16, four_d=True, t=25.0)
+    roofline = roofline_block(res["stats"], res["stage_ms"], res["warm_ms"], n, res["ms_per_step"], tfile(tag), one)
+
+    def side_block(r, o, workload, nn, ptag):
+        st_ = r["stats"]
+        return {"workload": workload, "splats": nn, "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "splats/s", "windows_ms_per_step": r["windows_ms_per_step"],
+                "tile_list_entries": st_["entries"], "longest_tile_list": st_["longest_list"], "unordered_draws": st_["unordered_draws"], "staged_list_draws": st_["slotted_draws"],
+                "depth_sort_passes": st_["depth_sort_passes"], "record_bytes_read_by_projection": st_["record_read_bytes"],
+                "aborted_frames_in_timed_windows": r["aborted_in_timed_windows"], "timed_window_attempts": r["timed_window_attempts"],
+                "latency_ms_one_lane": round(o["ms_per_step"], 5) if o else None,
+                "roofline": roofline_block(st_, r["stage_ms"], r["warm_ms"], nn, r["ms_per_step"], tfile(ptag), o)}
+    c3 = side_block(r3, one3, "10,000,000 random 3D splats in a 400^3 cube, single 1080p frame (BASELINE.json configs[2])", n3, "c3") if r3 else None
+    c4 = side_block(r4, one4, "1,000,000 4D splats (BASELINE.json configs[3]'s set: mu_t ~ U[0,50], lifetime ~ U[0.5,2], velocity ~ U[-5,5]^3) at t = 25, single 1080p frame, ONE GPU", n, "c4") if r4 else None
     cpu = None if args.no_cpu_baseline else cpu_baseline(rec, cam, view, proj)
     st = res["stats"]
     return {
@@ -306,14 +341,17 @@ def single_gpu(args, gs4d, scenes, device):
         "dtype": "f32", "data": "synthetic",
         "timing": f"median of {args.windows} windows of {args.steps} steps, each window between two synchronisations; a step is pipelined throughput ({st['lanes']} frame lanes in flight)",
         "windows_ms_per_step": res["windows_ms_per_step"],
-        "latency_ms_one_lane": latency,
+        "timed_window_attempts": res["timed_window_attempts"],
+        "latency_ms_one_lane": round(one["ms_per_step"], 5) if one else None,
         "config": {"workload": f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else ""),
                    "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": 1, "frame_lanes": st["lanes"],
-                   "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "overflow_reruns": st["reruns"],
-                   "aborted_frames_in_timed_windows": res["aborted_in_timed_windows"], "key_index_buffer_pairs": kb},
+                   "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "staged_list_draws": st["slotted_draws"], "overflow_reruns": st["reruns"],
+                   "depth_sort_passes": st["depth_sort_passes"], "record_bytes_read_by_projection": st["record_read_bytes"],
+                   "aborted_frames_in_timed_windows": res["aborted_in_timed_windows"], "key_index_buffer_pairs": kb, "lane_streams_rejected_at_create": st["lane_streams_rejected"], "lanes_sharing_a_hardware_queue": st["lanes_sharing_a_queue"]},
         "one_key_index_pair": one_pair,
         "roofline": roofline,
         "c3": c3,
+        "c4_n1": c4,
         "cpu_baseline": cpu,
     }
 
@@ -335,20 +373,44 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend)
-    # A torch stream of our own becomes torch's current stream AND the context's caller stream: a packed frame is ordered before the
-    # gather that sends it, and the next pack into the same slot after the gather that still reads it.  (Not torch's default stream:
-    # its handle is NULL, which gs4d_set_stream reads as "no caller stream" — round 1 and early round 2 passed exactly that.)
-    # ... in the LOWEST priority class when there are peers to send to: HIP keeps a pool of hardware queues per class and a queue executes in order, so
-    # in the default class the stream shares a queue with one frame lane and a millisecond-long send stalls that lane (emulated on one GPU with
-    # gs4d_sweep --fake-comm-us 150: 68.6 ms per sweep in the default class, 53.3 in the highest, 46.5 in the lowest)
-    comm_stream = torch.cuda.Stream(priority=torch.cuda.Stream.priority_range()[0]) if world > 1 else torch.cuda.Stream()
+    # A stream of our own becomes torch's current stream AND the context's caller stream: a packed frame is ordered before the gather that
+    # sends it, and the next pack into the same slot after the gather that still reads it.  (Not torch's default stream: its handle is NULL,
+    # which gs4d_set_stream reads as "no caller stream".)
+    # Priority: with peers to send to, the stream is created in HIP's LOWEST priority class — by hipStreamCreateWithPriority itself and wrapped
+    # as a torch ExternalStream: torch.cuda.Stream(priority=...) cannot do it on ROCm (c10/hip/HIPStream.h maps the least priority to 0, the
+    # default class: the round-3 line claimed a class it did not have).  HIP keeps a pool of hardware queues per class and a queue executes in
+    # order; in the default class this stream would share a queue with one frame lane (emulated on one GPU with gs4d_sweep --fake-comm-us 150:
+    # 68.6 ms per sweep in the default class, 46.5 in the lowest).  What runs on it: the RGBA8 packs' hand-off events and whatever
+    # the process group orders against torch's current stream.  The RCCL kernels themselves run on ProcessGroupNCCL's own internal stream (default
+    # class, not ours to choose from Python) — `comm.rccl_kernels_on` in the line says so; host/gs4d_sweep.cpp, which calls ncclSend/ncclRecv
+    # itself on a stream it created, is the host where the transfer really sits in the lowest class.
+    prio_info = {"requested": "default", "actual": None, "range_least_greatest": None}
+    comm_stream = None
+    if world > 1 and backend == "nccl":
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+            assert hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) == 0
+            raw = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithPriority(ctypes.byref(raw), ctypes.c_uint(1), ctypes.c_int(least.value)) == 0      # hipStreamNonBlocking
+            comm_stream = torch.cuda.ExternalStream(raw.value, device=torch.device("cuda", local_rank))
+            got = ctypes.c_int(0)
+            hip.hipStreamGetPriority(raw, ctypes.byref(got))
+            prio_info = {"requested": "lowest", "actual": got.value, "range_least_greatest": [least.value, greatest.value]}
+        except Exception as e:      # noqa: BLE001
+            prio_info = {"requested": "lowest", "actual": None, "error": repr(e)}
+            comm_stream = None
+    if comm_stream is None:
+        comm_stream = torch.cuda.Stream()
     torch.cuda.set_stream(comm_stream)
     assert comm_stream.cuda_stream != 0
     ctx.set_stream(comm_stream.cuda_stream)
     gdev = "cuda" if backend == "nccl" else "cpu"
     G = max(1, args.gather_every)
-    mine = sharding.frames_for_rank(SWEEP_FRAMES, rank, world)            # frame k -> rank k mod world
-    most = len(sharding.frames_for_rank(SWEEP_FRAMES, 0, world))          # ranks with fewer frames pad their last batch
+    pct = args.rank0_frames_pct if args.rank0_frames_pct is not None else sharding.default_rank0_pct(world)
+    mine = sharding.frames_for_rank(SWEEP_FRAMES, rank, world, pct)       # pct = 100: frame k -> rank k mod world
+    most = sharding.most_frames(SWEEP_FRAMES, world, pct)                 # ranks with fewer frames pad their last batches
     # two batch buffers, used alternately: the packs of batch b + 1 fill one while the gather of batch b still reads the other.  A pack waits
     # only for the event recorded behind the gather that last read ITS buffer (gs4d_read_frame_rgba8_device_after), not for the comm stream.
     batch = [torch.zeros((G, H * W), dtype=torch.int32, device="cuda") for _ in range(2)]
@@ -356,42 +418,29 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
     free_ev = [torch.cuda.Event(), torch.cuda.Event()]
     free_valid = [False, False]
     pipelined = ctx.stats()["lanes"] >= 2                                 # with one frame lane there is no previous image to read
-    schedule = {p: (b, lo, hi) for p, b, lo, hi in sharding.gather_schedule(most, G)}      # after how many presentations a gather goes out, and which slots of its batch
     comm = {"busy_ms": 0.0, "tail_ms": 0.0, "pairs": []}
 
+    def render(j):
+        sc.frame(sharding.sweep_time(mine[j], SWEEP_FRAMES))
+
+    def pack(j, frames_back, x, slot):
+        ctx.read_frame_rgba8_device_after(frames_back, batch[x][slot].data_ptr(), H * W * 4, free_ev[x].cuda_event if free_valid[x] else None)
+
+    def gather(x, lo, hi, _first):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(comm_stream)
+        part = batch[x][lo:hi]
+        sharding.gather_frames(dist, part if backend == "nccl" else part.cpu(), [g[lo:hi] for g in gathered[x]] if rank == 0 else None, dst=0)
+        e1.record(comm_stream)
+        free_ev[x].record(comm_stream)
+        free_valid[x] = True
+        comm["pairs"].append((e0, e1))
+
     def sweep(_k):
-        """One step: this rank's frames of the 256-frame sweep.  Presentation is software-pipelined as a swap chain is — frame j is queued
-        first, then frame j-1 (the previous image) is packed to RGBA8 into the batch — and every G presented frames the batch is gathered
-        on rank 0 (the last batch of the sweep in quarters: sharding.gather_schedule).  Every rank counts `most` presentations (a rank with one frame fewer skips the read of its last slot), so all ranks
-        make the same collective calls whatever the world size."""
-        state = {"p": 0}
-
-        def present(j, frames_back):
-            x = (state["p"] // G) & 1
-            if j < len(mine):
-                ctx.read_frame_rgba8_device_after(frames_back, batch[x][state["p"] % G].data_ptr(), H * W * 4, free_ev[x].cuda_event if free_valid[x] else None)
-            state["p"] += 1
-            if state["p"] in schedule:
-                _b, lo, hi = schedule[state["p"]]
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(comm_stream)
-                part = batch[x][lo:hi]
-                sharding.gather_frames(dist, part if backend == "nccl" else part.cpu(), [g[lo:hi] for g in gathered[x]] if rank == 0 else None, dst=0)
-                e1.record(comm_stream)
-                free_ev[x].record(comm_stream)
-                free_valid[x] = True
-                comm["pairs"].append((e0, e1))
-
-        for j in range(most):
-            rendered = j < len(mine)
-            if rendered:
-                sc.frame(sharding.sweep_time(mine[j], SWEEP_FRAMES))
-            if not pipelined:
-                present(j, 0)
-            elif j >= 1:
-                present(j - 1, 1 if rendered else 0)      # no new frame was started: frame j-1 is still the current image
-        if pipelined:
-            present(most - 1, 0)                          # the last frame of the sweep is presented inside the sweep
+        """One step: this rank's frames of the 256-frame sweep (sharding.run_sweep: the presentation loop the gloo tests drive too).  Presentation is
+        software-pipelined as a swap chain is, every G presented frames the batch is gathered on rank 0 (the last batch of the sweep in quarters),
+        every rank counts `most` presentations, so all ranks make the same collective calls whatever the deal."""
+        sharding.run_sweep(len(mine), most, G, pipelined, render, pack, gather)
 
     def sweep_one_gpu(_k):
         """The same sweep with every frame on THIS GPU and nothing sent anywhere (frames packed to RGBA8 as above): the N = 1 point of the
@@ -456,11 +505,14 @@ def multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend):
         "dtype": "f32", "data": "synthetic",
         "timing": f"median of {args.windows} windows of {args.steps} steps (a step = the whole {SWEEP_FRAMES}-frame sweep), barrier + synchronize around every window, maximum over ranks",
         "windows_ms_per_step": [round(1e3 * s / args.steps, 4) for s in secs],
-        "config": {"workload": "1,000,000 4D splats, 256-frame time sweep t_k = 50 k / 255, frame k on rank k mod N, RGBA8 frames gathered on rank 0 (BASELINE.json configs[3])",
+        "config": {"workload": "1,000,000 4D splats, 256-frame time sweep t_k = 50 k / 255, frames dealt to the ranks, RGBA8 frames gathered on rank 0 (BASELINE.json configs[3])",
                    "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": SWEEP_FRAMES, "ms_per_frame": med / SWEEP_FRAMES,
+                   "rank0_frames_pct_of_equal_share": pct, "frames_per_rank": [len(sharding.frames_for_rank(SWEEP_FRAMES, r, world, pct)) for r in range(world)],
+                   "gather_format": "RGBA8 (presentation format, 4 B/pixel): the float image the <= 1e-4 parity bar is stated on stays on the rendering GPU",
                    "frames_per_gather_per_rank": G, "batch_buffers": 2, "frame_lanes": stats["lanes"], "tile_list_entries": stats["entries"], "overflow_reruns": stats["reruns"],
                    "aborted_frames": stats["aborted_discarded"]},
         "comm": {"stream_busy_ms_per_sweep_per_rank": [round(float(t[0]), 3) for t in all_comm], "stream_tail_ms_per_window_per_rank": [round(float(t[1]), 3) for t in all_comm],
+                 "stream_priority": prio_info, "rccl_kernels_on": "ProcessGroupNCCL's internal stream (default priority class); the hand-off events and the packs' ordering are on the stream above",
                  "note": "busy: sum of the gathers' durations on the comm stream (for a sender that includes waiting for rank 0's matching receive); tail: time the comm stream ran on after the rank's last frame was rendered (exposed)"},
         "roofline": {"bound": "hbm", "kernel": None, "achieved": round(frame_ach, 2), "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(frame_ach / (HBM_PEAK_GBS * world), 5),
                      "traffic": None, "note": "whole-job algorithmic bytes over all ranks against N x 8 TB/s; the per-kernel figure is in the N = 1 line"},

@@ -517,3 +517,48 @@ def test_tile_rectangles_beyond_the_packed_range(gs4d, oracle, monkeypatch, path
     assert ((x1[drawn] // 8 - x0[drawn] // 8) >= 63).any()       # ... and that are wider than it holds
     assert linf(img, eimg) <= TOL
     assert np.abs(eimg[:, 8184:] - np.array(gs4d.CLEAR_COLOR, np.float32)).max() > 0.05      # something is drawn out there
+
+
+def test_two_contexts_created_and_used_on_two_threads(gs4d, oracle):
+    """No process-wide state behind the C ABI: two threads each create a context of their own (gs4d_create may name any device) and run whole
+    frames — key loop, sort, draw — at the same time.  (Round 3 cached the persistent sort's workgroup count in a function-local static: racy
+    here, and wrong for contexts on two different devices.)  ctypes releases the GIL for the duration of a call, so the calls do overlap."""
+    import threading
+    W, H = 640, 360
+    sizes = (150_000, 40_000)
+    results, errors = {}, []
+
+    def worker(k, n):
+        try:
+            pos, q, scale, rgba = scenes.cube_params(n, seed=100 + k)
+            rec = gs4d.build_records_3d(pos, q, scale * 2.0, rgba)
+            cam = scenes.CAM_CUBE
+            view = gs4d.look_at(cam[0], cam[1]); proj = gs4d.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
+            ctx = gs4d.Context(W, H)
+            ctx.set_clear_color(gs4d.CLEAR_COLOR)
+            db, kb, ib = ctx.buffer(rec), ctx.buffer(nbytes=4 * n), ctx.buffer(nbytes=4 * n)
+            for _ in range(6):
+                ctx.clear()
+                ctx.set_uniforms(time=0.0, min_opacity=0.0, view=view, proj=proj)
+                ctx.keygen(db, 0.0, cam[0], kb, ib, n)
+                ctx.sort_pairs(kb, ib, n)
+                ctx.set_mode(gs4d.MODE_4D_SORTED)
+                ctx.bind(1, ib); ctx.bind(2, db)
+                ctx.draw_instanced(n)
+            results[k] = (rec, ctx.read_pixels(), ctx.read(ib, np.uint32, n), view, proj, cam)
+            ctx.close()
+        except Exception as e:      # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k, n)) for k, n in enumerate(sizes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert len(results) == len(sizes)
+    for k in results:
+        rec, img, perm, view, proj, cam = results[k]
+        eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+        assert np.array_equal(perm, eperm)
+        assert np.abs(img.astype(np.float64) - eimg).max() <= 1e-4

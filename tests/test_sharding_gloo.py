@@ -71,6 +71,87 @@ def test_round_robin_partition():
     assert sh.sweep_time(0, 256) == 0.0 and sh.sweep_time(255, 256) == 50.0
 
 
+def test_uneven_deal_partitions_the_sweep():
+    """rank 0 renders fewer frames (it also receives everybody's): every frame has exactly one owner, rank 0's are spread over the sweep"""
+    sh = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
+    assert sh.default_rank0_pct(1) == 100 and sh.default_rank0_pct(2) == 98 and sh.default_rank0_pct(8) == 87
+    for world, pct in ((2, 98), (3, 50), (8, 87), (8, 0), (4, 100)):
+        own = sh.deal(256, world, pct)
+        assert len(own) == 256 and set(own) <= set(range(world))
+        seen = sorted(f for r in range(world) for f in sh.frames_for_rank(256, r, world, pct))
+        assert seen == list(range(256))
+        n0 = len(sh.frames_for_rank(256, 0, world, pct))
+        assert n0 == int(round(256 / world * pct / 100.0))
+        rest = [len(sh.frames_for_rank(256, r, world, pct)) for r in range(1, world)]
+        assert max(rest) - min(rest) <= 1 and sh.most_frames(256, world, pct) == max([n0] + rest)
+        if 0 < n0 < 256:
+            f0 = sh.frames_for_rank(256, 0, world, pct)
+            gaps = np.diff(f0)
+            assert gaps.max() - gaps.min() <= 1                  # evenly spread
+    assert sh.deal(256, 8, 100) == [k % 8 for k in range(256)]
+
+
+NF2, G2 = 22, 4
+
+
+def _sweep_worker(rank, world, port, out, pct, pipelined):
+    """bench.py's N > 1 presentation loop (sharding.run_sweep) under gloo: two batch buffers, the tapered last batch, an uneven deal.  A frame is
+    a small tensor filled with its frame number; rank 0 rebuilds the sweep from what it received."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path[:0] = [HERE, ROOT]
+    sh = importlib.import_module("4dgaussiansplatrendering_amd.sharding")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = sh.frames_for_rank(NF2, rank, world, pct)
+    most = sh.most_frames(NF2, world, pct)
+    batch = [torch.full((G2, 5), -1, dtype=torch.int32) for _ in range(2)]
+    gathered = [[torch.empty((G2, 5), dtype=torch.int32) for _ in range(world)] for _ in range(2)] if rank == 0 else [None, None]
+    images = []                                    # the swap chain: images[-1] is the current one
+    received = {}
+    busy = [False, False]                          # batch buffer x has been handed to a gather and not been refilled since
+
+    def render(j):
+        images.append(mine[j])
+
+    def pack(j, frames_back, x, slot):
+        assert images[-1 - frames_back] == mine[j], "the pack reads the wrong image of the swap chain"
+        batch[x][slot] = mine[j]
+        busy[x] = False
+
+    def gather(x, lo, hi, first):
+        part = batch[x][lo:hi].clone()
+        sh.gather_frames(dist, part, [g[lo:hi] for g in gathered[x]] if rank == 0 else None, dst=0)
+        busy[x] = True
+        if rank == 0:
+            for r in range(world):
+                fr = sh.frames_for_rank(NF2, r, world, pct)
+                for s in range(lo, hi):
+                    pnum = first + (s - lo)
+                    if pnum < len(fr):
+                        v = gathered[x][r][s]
+                        assert int(v.min()) == int(v.max()) == fr[pnum], (r, s, pnum, v)
+                        received[fr[pnum]] = int(v[0])
+
+    calls = sh.run_sweep(len(mine), most, G2, pipelined, render, pack, gather)
+    every = [None] * world
+    dist.all_gather_object(every, calls)
+    assert all(c == every[0] for c in every), "the ranks made different collective calls"
+    assert calls == [(p, (p - 1) // G2 & 1, lo, hi) for p, b, lo, hi in sh.gather_schedule(most, G2)]
+    dist.barrier()
+    if rank == 0:
+        assert sorted(received) == list(range(NF2)) and all(received[k] == k for k in received)
+        np.save(out, np.array([len(calls), most], np.int64))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pct,pipelined", [(2, 100, True), (3, 50, True), (3, 70, False), (2, 0, True)])
+def test_sweep_presentation_loop_with_two_batch_buffers(tmp_path, world, pct, pipelined):
+    out = str(tmp_path / "sweep.npy")
+    port = 33500 + (os.getpid() % 2000) + world * 7 + pct % 5
+    mp.spawn(_sweep_worker, args=(world, port, out, pct, pipelined), nprocs=world, join=True)
+    ncalls, most = np.load(out)
+    assert ncalls >= (most + G2 - 1) // G2
+
+
 def _band_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path[:0] = [HERE, ROOT]
