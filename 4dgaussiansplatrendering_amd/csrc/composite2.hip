@@ -17,6 +17,8 @@
 // checked for equal neighbours; only then is it sorted on the record index first and on the key again.
 #include "composite_common.h"
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 namespace gs4d {
 
@@ -74,7 +76,8 @@ template <bool PREMULT_C, int PER>
 __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
                                                      const uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, int tiles_x, int W, int H, uint32_t* __restrict__ tstate, uint32_t epoch, float4 clear,
                                                      float4* __restrict__ fb, int key_passes, int rec_passes, uint32_t slabs,
-                                                     const uint4* __restrict__ bstat, uint32_t nb, const uint32_t* __restrict__ sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap) {
+                                                     const uint4* __restrict__ bstat, uint32_t nb, const uint32_t* __restrict__ sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap,
+                                                     unsigned long long* __restrict__ stamps) {
     // the sort's key plane and the blend's record staging never live at the same time: one piece of LDS serves both
     constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
     __shared__ __attribute__((aligned(16))) uint32_t sh_a[SHARED_WORDS];
@@ -86,12 +89,22 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     uint32_t tile;
     const bool real = composite_tile(blockIdx.x, tiles_x, (H + TILE - 1) / TILE, tile);     // false: padding of the XCD-aware grid
     const uint32_t lane = threadIdx.x;
+#ifdef GS4D_TUNING
+    const unsigned long long st0 = wall_clock64(); unsigned long long st1 = 0, st2 = 0; uint32_t stE = 0;      // per-tile stamps (100 MHz): start, list ordered, (end), entries
+#endif
     // what the list kernels found out — entries, longest list, abort flags — goes to the host from here (pinned, mapped memory behind
     // the lane's event): they are complete now, and none of them has to wait for a hand-off of its own
     // A staged draw (slot_seq != 0, tilelist.hip) has no scan kernel that could have added anything up: its verdict is the abort word and the
     // per-bucket statistics {entries, longest run, longest list} and per-segment entry counts, reduced here.  An exact draw reports its statistics
     // the same way (they size the blocks, runs and buckets of the staged draws that follow) beside the totals its scan kernel left.
-    const bool aborted = slot_seq ? total[TL_ABORT_WORD] == slot_seq : total[1] != 0u;
+    // Everything the tile needs before it can ask for its list is requested HERE, in one go — the verdict word, the tile's table row, its state
+    // word: three independent loads, one round trip.  (Issued one behind the other's branch they were three round trips: per-tile stamps of a
+    // TUNING build showed 3.9 us between a workgroup's start and its list being in order for lists of <= 64 entries — tools/v2_timeline.py.)
+    const uint32_t verdict = slot_seq ? total[TL_ABORT_WORD] : total[1];
+    uint32_t my_start = 0u, my_cnt = 0u;                    // lane s: sub-list s of this tile (one load for the whole table row)
+    if (real && lane < slabs) { my_start = tstart[(size_t)tile * slabs + lane]; my_cnt = tcnt[(size_t)tile * slabs + lane]; }
+    const uint32_t tstate_word = real ? tstate[tile] : 0u;
+    const bool aborted = slot_seq ? verdict == slot_seq : verdict != 0u;
     if (blockIdx.x == 0u) {
         unsigned long long sum = 0ull; uint32_t mrun = 0u, mbucket = 0u, mlist = 0u, mseg = 0u;
         if (bstat) for (uint32_t b = lane; b < nb; b += 64u) { const uint4 v = bstat[b]; sum += v.x; mrun = max(mrun, v.y); mbucket = max(mbucket, v.x); mlist = max(mlist, v.z); }
@@ -118,10 +131,8 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     const float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
     float T = 1.0f, Cr = 0.0f, Cg = 0.0f, Cb = 0.0f, A = 0.0f;
     // the tile's list is `slabs` sub-lists by the top bits of the key; larger key = nearer: the last slab is blended first
-    uint32_t my_start = 0u, my_cnt = 0u;                    // lane s: sub-list s of this tile (one load for the whole table row)
-    if (lane < slabs) { my_start = tstart[(size_t)tile * slabs + lane]; my_cnt = tcnt[(size_t)tile * slabs + lane]; }
     if (__ballot(my_cnt != 0u) == 0ull) return;             // nothing is drawn on this tile: its pixels, or its being clear (composite.hip: tile state), stay as they are
-    const bool fb_is_clear = tstate[tile] != epoch;         // uniform: the tile's pixels are not in memory yet
+    const bool fb_is_clear = tstate_word != epoch;          // uniform: the tile's pixels are not in memory yet
     for (int sb = (int)slabs - 1; sb >= 0; --sb) {
         const uint32_t start = __shfl(my_start, sb, 64);
         const uint32_t E = min((uint32_t)__shfl(my_cnt, sb, 64), (uint32_t)(64 * PER));         // k_bucket_tiles guarantees the bound; min() keeps a broken promise inside LDS
@@ -153,6 +164,10 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
             if (lane == 0) er[0] = entries[start].y;
             __syncthreads();
         }
+#ifdef GS4D_TUNING
+        if (!st1) st1 = wall_clock64();
+        stE += E;
+#endif
         for (uint32_t hi = E; hi > 0u;) {
             const uint32_t c = min(64u, hi);
             const uint32_t rec = lane < c ? er[hi - 1u - lane] : 0u;       // lane s holds list entry hi-1-s : s = 0 is the front-most of the chunk
@@ -168,12 +183,15 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
         fb[o] = make_float4(Cr + T * d.x, Cg + T * d.y, Cb + T * d.z, A + T * d.w);
     }
     if (lane == 0u) tstate[tile] = epoch;
+#ifdef GS4D_TUNING
+    if (stamps && lane == 0u) { st2 = wall_clock64(); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw)); unsigned long long* o = stamps + (size_t)blockIdx.x * 6; o[0] = st0; o[1] = st1; o[2] = st2; o[3] = stE; o[4] = tile; o[5] = hw; }
+#endif
 }
 
 template <bool PREMULT_C>
 static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int W, int H,
-                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs, const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap) {
-#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap)
+                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs, const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap, unsigned long long* stamps) {
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap, stamps)
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
@@ -199,8 +217,27 @@ hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* 
 #ifdef GS4D_TUNING
     { static const bool nosort = getenv("GS4D_V2_NOSORT") != nullptr; if (nosort) kp = rp = 0; }      // ablation: what the wave-local list sort costs the kernel (the image is then wrong)
 #endif
-    return premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap)
-                     : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap);
+    unsigned long long* stamps = nullptr;
+#ifdef GS4D_TUNING
+    // tuning aid: per-tile wall-clock stamps of the GS4D_V2_STAMP_CALL-th launch, dumped to GS4D_V2_STAMP_FILE (tools/v2_timeline.py reads it)
+    static const char* stampf = getenv("GS4D_V2_STAMP_FILE");
+    static const int stamp_call = getenv("GS4D_V2_STAMP_CALL") ? atoi(getenv("GS4D_V2_STAMP_CALL")) : 40;
+    static int calls = 0;
+    const bool stamp_now = stampf && ++calls == stamp_call;
+    if (stamp_now && (hipMalloc(&stamps, (size_t)grid.x * 48) != hipSuccess || hipMemsetAsync(stamps, 0, (size_t)grid.x * 48, st) != hipSuccess)) stamps = nullptr;
+#endif
+    const hipError_t le = premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap, stamps)
+                                    : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap, stamps);
+#ifdef GS4D_TUNING
+    if (stamps) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> hs((size_t)grid.x * 6);
+        (void)hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(stampf, "w")) { for (uint32_t t = 0; t < grid.x; ++t) { for (int k = 0; k < 6; ++k) fprintf(f, "%llu ", hs[(size_t)t * 6 + k]); fprintf(f, "\n"); } fclose(f); }
+        (void)hipFree(stamps);
+    }
+#endif
+    return le;
 }
 
 } // namespace gs4d

@@ -263,12 +263,18 @@ def main():
     ap.add_argument("--rank0-frames-pct", type=int, default=None, help="N>1: rank 0 renders this percentage of an equal share of the sweep (it also receives every other rank's frames); default: sharding.default_rank0_pct(N)")
     ap.add_argument("--lanes", type=int, default=None, help="frame lanes of the context (default: the library's, 4); experiments")
     ap.add_argument("--keybufs", type=int, default=None, help="key / sort-index buffer pairs the application cycles through (default: one per lane)")
-    ap.add_argument("--no-c3", action="store_true", help="N=1: skip the configs[2] block (10^7 splats)")
+    ap.add_argument("--four-d", action="store_true", help="N=1: the main workload is configs[3]'s set of true 4D splats at t = 25 instead of the static cube (profiling the c4_n1 block's kernels: tools/profile_round.sh)")
+    ap.add_argument("--no-c3", action="store_true", help="N=1: skip the configs[2] and c4_n1 blocks (10^7 splats; 10^6 4D splats)")
     ap.add_argument("--no-latency", action="store_true", help="N=1: skip the one-lane frame time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true", help="do not record per-stage HIP events in the timed windows")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries talk there too (RCCL prints a version banner at communicator creation on some boxes): keep
+    # the real stdout for the line and point file descriptor 1 at stderr for everything else.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -287,36 +293,39 @@ def main():
         out = single_gpu(args, gs4d, scenes, local_rank)
     else:
         out = multi_gpu(args, gs4d, scenes, torch, rank, local_rank, world, backend)
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
+    os.close(line_fd)
 
 
 def single_gpu(args, gs4d, scenes, device):
     n = args.splats
     kb = args.keybufs or args.lanes or 4          # one pair per frame lane (the library default is 4 lanes)
-    res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
-    tag = "c2" if n == 1_000_000 else "c3" if n == 10_000_000 else "x"
+    fd = dict(four_d=True, t=25.0) if args.four_d else {}
+    res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb, **fd)
+    tag = "c4" if args.four_d else "c2" if n == 1_000_000 else "c3" if n == 10_000_000 else "x"
     tfile = lambda t: os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{t}.json")
     # The four-lane side measurements come first, the one-lane ones last: a context created after a context with another number of frame
     # lanes runs ~10 % slower (tools/order_effect.py: 0.110 -> 0.122 ms/frame after one one-lane context has been created and closed; HIP maps
     # the lanes' streams onto its hardware queues differently then) — an artefact of this process's history, not of the workload.
     n3 = 10_000_000
-    side = not args.no_c3 and n == 1_000_000
+    side = not args.no_c3 and n == 1_000_000 and not args.four_d
     r3 = r4 = None
     if side:
-        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 5, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
+        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 8, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
         # configs[3]'s workload on ONE GPU: 10^6 true 4D splats (96-byte records: nothing of sig is constant or symmetric-by-construction here), t mid-sweep
-        r4, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 100), 10, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb, four_d=True, t=25.0)
+        r4, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 100), 24, 5, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb, four_d=True, t=25.0)
     one_pair = None
     if not args.no_latency:
         # the reference's own buffer layout: ONE key / index pair for every frame (Scenes.h m_key_buf / m_values_buf).  Frame f + 1 writes the
         # buffers frame f's sort is still filling: the lanes order themselves on the device (events), consecutive frames overlap less.
-        r1, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=args.lanes, keybufs=1)
+        r1, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=args.lanes, keybufs=1, **fd)
         one_pair = {"ms_per_step": round(r1["ms_per_step"], 5), "value": r1["value"], "unit": "splats/s",
                     "note": "same workload with one key / sort-index buffer pair instead of one per frame lane (the reference's layout, Scenes.h:241-247): the drop-in figure"}
     one = one3 = one4 = None
     if not args.no_latency:
-        one, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=1, steady_stages=16)
+        one, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=1, steady_stages=16, **fd)
         if side:
             one3, _, _ = measure_single(gs4d, scenes, n3, 10, 5, 3, device, stage_events=False, lanes=1, steady_stages=8)
             one4, _, _ = measure_single(gs4d, scenes, n, 30, 10, 3, device, stage_events=False, lanes=1, steady_stages=16, four_d=True, t=25.0)
@@ -343,7 +352,8 @@ def single_gpu(args, gs4d, scenes, device):
         "windows_ms_per_step": res["windows_ms_per_step"],
         "timed_window_attempts": res["timed_window_attempts"],
         "latency_ms_one_lane": round(one["ms_per_step"], 5) if one else None,
-        "config": {"workload": f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else ""),
+        "config": {"workload": (f"{n:,} 4D splats of BASELINE.json configs[3]'s set at t = 25, single 1080p frame, one GPU" if args.four_d else
+                                f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else "")),
                    "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": 1, "frame_lanes": st["lanes"],
                    "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "staged_list_draws": st["slotted_draws"], "overflow_reruns": st["reruns"],
                    "depth_sort_passes": st["depth_sort_passes"], "record_bytes_read_by_projection": st["record_read_bytes"],

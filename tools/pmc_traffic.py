@@ -11,7 +11,7 @@ usage: pmc_traffic.py <fetch_dir> <write_dir> <frames> <out.json>"""
 import csv, glob, json, sys
 from collections import defaultdict
 
-GATHER = ("k_composite", "k_bin_emit")          # read mostly by 64-B-sector gathers: FETCH_SIZE x 1
+GATHER = ("k_composite", "k_bin_emit", "k_bucket_tiles_staged")          # read mostly by 64-B-sector gathers (8-byte loads, one run per lane): FETCH_SIZE x 1
 
 
 def load(d, counter):

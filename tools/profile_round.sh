@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage: tools/profile_round.sh <tag> <splats> <steps>   (on the GPU box, from the repo root)  -> gpurun_out/<tag>/
+# usage: tools/profile_round.sh <tag> <splats> <steps> [extra bench.py flags, e.g. --four-d]   (on the GPU box, from the repo root)  -> gpurun_out/<tag>/
 # one evidence set for profiles/: the bench line of the same command, rocprofv3 --kernel-trace --stats with the frame lanes overlapping and
 # with one lane (every kernel alone), and the two --pmc passes (FETCH_SIZE, WRITE_SIZE: separate runs, no trace domains) reduced by pmc_traffic.py
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1; n=$2; steps=$3; warm=5; frames=$((steps+warm))
 out=gpurun_out/$tag; mkdir -p $out
-common="--splats $n --no-cpu-baseline --no-c3 --no-latency"
+extra="${@:4}"
+common="--splats $n --no-cpu-baseline --no-c3 --no-latency $extra"
 python3 bench.py $common --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $common --steps $steps --warmup $warm --windows 1 > $out/trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 bench.py $common --steps $steps --warmup $warm --windows 1 > $out/pmc_fetch.log 2>&1 || exit 1
