@@ -677,12 +677,14 @@ hipError_t radix_sort_pairs(hipStream_t st, SortScratch& s, uint32_t* keys, uint
     const int rb = have_hist ? s.hist_rb : sort_plan_rb(s, n, key_bits);
     if (rb != 8 && rb != 9) return hipErrorInvalidValue;
     const int passes = sort_plan_passes(key_bits, rb);
-    // 8192-key tiles: 1024 threads x 8 keys (streaming stores) for small sorts, 512 x 16 (ordinary stores) beyond 1.5M keys.  Alone, a pass over
-    // 10^6 keys costs the same with 4096-key tiles of 512 threads (12.7 us either way, round 3); with four frame lanes overlapping the
-    // larger tile — half as many workgroups waiting in the look-back beside the other lanes' kernels — gives 2-3 % more frames per second
-    // (0.1153 against 0.1184 ms per frame, two runs each); 2048-key tiles are slower alone (20.3 us) and overlapped (0.1405).
+    // 8192-key tiles of 512 threads x 16 keys for every size.  Rounds 2-3 ran sorts of <= 1.5M keys as 1024 x 8 (the same 12.7 us per pass alone at 10^6 keys;
+    // 2-3 % more frames per second with the frame lanes overlapping, as the frame then was).  With this round's frame (staged tile lists: two launches fewer,
+    // a longer projection kernel) the 512-thread form wins by 3 % at C2 — 0.0980-0.0984 against 0.1010-0.1017 ms/frame, three alternating runs each; 512 x 12:
+    // 0.0983-0.0997; 512 x 8: 0.104; 256 x 16: 0.105 — and 1.4 % on the 4D set (0.1213 against 0.1231): a 16-wave workgroup finds a free CU later than an
+    // 8-wave one beside the other lanes' kernels.  2048-key tiles are slower alone (20.3 us) and overlapped.
     // 512 bins: the large sorts use 512 x 12 (48 KB of keys and values + 16 KB of per-wave counters: still two workgroups per CU).
-    int shape = s.shape_knob ? s.shape_knob : (n <= ((size_t)3 << 19) ? 3 : 5);
+    int shape = s.shape_knob ? s.shape_knob : 5;
+    (void)n;
     if (rb == 9 && shape == 5 && !s.shape_knob) shape = 6;
     const bool atomic_rank = s.rank_knob ? s.rank_knob == 2 : s.atomic_rank;
 #define GS4D_OS8(T, I) (atomic_rank ? onesweep<T, I, true, 8>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals) : onesweep<T, I, false, 8>(st, s, keys, vals, n, n_dev, passes, have_hist, identity_vals))
