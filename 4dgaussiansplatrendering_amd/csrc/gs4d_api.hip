@@ -459,7 +459,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             { static const char* ev = getenv("GS4D_STAGE_CPR"); if (ev && atoi(ev) >= 1) cpr = (uint64_t)atoi(ev); }      // experiment / test knob
             const uint64_t scap = ((uint64_t)c->slot_max_seg + c->slot_max_seg / 8 + 64 + 63) & ~63ull;
             const uint64_t bcap = ((uint64_t)c->slot_max_bucket + c->slot_max_bucket / 8 + 512 + 63) & ~63ull;
-            if (scap <= STAGE_MAX_SCAP && (uint64_t)L.tl.rows * cpr <= 4096 && (uint64_t)L.tl.nb * bcap < 0xFFFFFFF0ull) {
+            if (scap <= STAGE_MAX_SCAP && (uint64_t)L.tl.rows * cpr <= 4096 && (uint64_t)L.tl.nb * bcap < 0xFFFFFFF0ull) {      // (k_bucket_tiles_staged: up to 8 rounds of 512 chunks, or 4 of 1024)
                 HIPCHK(c, tile_lists_reserve_slots(L.s, L.tl, (size_t)L.tl.rows * scap));
                 L.tl.cpr = (uint32_t)cpr; L.tl.scap = (uint32_t)scap; L.tl.bcap = (uint32_t)bcap;
                 if (++L.tl.seq == 0u) L.tl.seq = 1u;

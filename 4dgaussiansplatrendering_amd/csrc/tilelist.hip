@@ -242,28 +242,33 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
 // keeps the chunks of its ROUNDS rounds in registers between counting and placing.  The tile lists of bucket b go to entries[b * bcap ...].
 // Statistics {entries, longest run, longest list} go to bstat[b]; a bucket that does not fit stores the draw's sequence number into *abort_word
 // (every writer stores the same value).
-template <int ROUNDS>
-__global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles_staged(const uint2* __restrict__ blocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t rows, uint32_t cpr, uint32_t scap,
+template <int ROUNDS, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bucket_tiles_staged(const uint2* __restrict__ blocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t rows, uint32_t cpr, uint32_t scap,
                                                                     uint32_t bcap, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift, uint32_t nc, uint32_t* __restrict__ tstart,
                                                                     uint32_t* __restrict__ tcnt, uint2* __restrict__ entries, uint4* __restrict__ bstat, uint32_t* __restrict__ abort_word, uint32_t seq, uint32_t hint) {
     extern __shared__ uint32_t cnt[];                      // [nc]
-    __shared__ uint32_t ws[BT_THREADS / 64], wm[BT_THREADS / 64];
+    __shared__ uint32_t ws[THREADS / 64], wm[THREADS / 64];
     __shared__ uint32_t rc[1024], ro[1024];                // the bucket's run counts and where each run starts (rows <= 1024: tile_lists_plan)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
     const uint32_t sl = (uint32_t)__ffs((int)slabs) - 1u;
-    for (uint32_t k = tid; k < nc; k += BT_THREADS) cnt[k] = 0u;
+    for (uint32_t k = tid; k < nc; k += THREADS) cnt[k] = 0u;
     // ---- the bucket's counts: total, longest run ----
-    const uint32_t myc = tid < rows ? hist[(size_t)b * rows + tid] : 0u;
-    rc[tid] = myc;
-    ro[tid] = tid < rows ? tid * scap + offs[(size_t)b * rows + tid] : 0u;
-    uint32_t tsum = myc, tmax = myc;
+    uint32_t tsum = 0, tmax = 0;
+#pragma unroll
+    for (int rr = 0; rr < 1024 / THREADS; ++rr) {
+        const uint32_t wseg = (uint32_t)rr * THREADS + tid;
+        const uint32_t myc = wseg < rows ? hist[(size_t)b * rows + wseg] : 0u;
+        rc[wseg] = myc;
+        ro[wseg] = wseg < rows ? wseg * scap + offs[(size_t)b * rows + wseg] : 0u;
+        tsum += myc; tmax = max(tmax, myc);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { tsum += __shfl_xor(tsum, off, 64); tmax = max(tmax, (uint32_t)__shfl_xor(tmax, off, 64)); }
     if (lane == 0u) { ws[w] = tsum; wm[w] = tmax; }
     __syncthreads();
     uint32_t T = 0, maxrun = 0;
 #pragma unroll
-    for (int k = 0; k < BT_THREADS / 64; ++k) { T += ws[k]; maxrun = max(maxrun, wm[k]); }
+    for (int k = 0; k < THREADS / 64; ++k) { T += ws[k]; maxrun = max(maxrun, wm[k]); }
     // (a segment that overflowed its block wrote no entries and raised the abort word itself; its counts are still true)
     const bool fits = maxrun <= 8u * cpr && T <= bcap;     // uniform
     if (!fits) {
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles_staged(const uint2*
     uint32_t ne[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const uint32_t q = (uint32_t)r * BT_THREADS + tid;
+        const uint32_t q = (uint32_t)r * THREADS + tid;
         ne[r] = 0u;
         if (q < nchunks) {
             const uint32_t run = q / cpr, s0 = (q - run * cpr) << 3;
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles_staged(const uint2*
         for (int k = 0; k < 8; ++k) if ((uint32_t)k < ne[r]) atomicAdd(&cnt[counter_of(e[r][k])], 1u);
     __syncthreads();
     // exclusive scan of the nc counters, the tile table, the longest sub-list (as k_bucket_tiles)
-    const uint32_t cpt = (nc + BT_THREADS - 1u) / BT_THREADS, q0c = tid * cpt;
+    const uint32_t cpt = (nc + THREADS - 1u) / THREADS, q0c = tid * cpt;
     uint32_t sum = 0, mx = 0;
     for (uint32_t k = 0; k < cpt; ++k) { const uint32_t q = q0c + k; const uint32_t c = q < nc ? cnt[q] : 0u; sum += c; mx = max(mx, c); }
     uint32_t inc = sum;
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles_staged(const uint2*
     __syncthreads();
     uint32_t wbase = 0, longest = 0;
 #pragma unroll
-    for (int k = 0; k < BT_THREADS / 64; ++k) { if ((unsigned)k < w) wbase += ws[k]; longest = max(longest, wm[k]); }
+    for (int k = 0; k < THREADS / 64; ++k) { if ((unsigned)k < w) wbase += ws[k]; longest = max(longest, wm[k]); }
     const uint32_t lo = b * bcap;
     uint32_t run = lo + wbase + inc - sum;
     for (uint32_t k = 0; k < cpt; ++k) {
@@ -427,15 +432,31 @@ hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint
 }
 
 hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint2* entries, uint32_t hint) {
-    const uint32_t rounds = (t.rows * t.cpr + BT_THREADS - 1) / BT_THREADS;
-#define GS4D_BTS(R) k_bucket_tiles_staged<R><<<dim3(t.nb), dim3(BT_THREADS), t.counters * 4u, st>>>(t.slot_mem, t.hist, t.hist + t.hist_cap, t.rows, t.cpr, t.scap, t.bcap, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, \
+    // 512 threads: the same 18 us alone as with 1024, 4 % more frames per second with the frame lanes overlapping (0.0955-0.0961 against 0.0992-0.1018 ms per
+    // frame at C2, alternating runs) — an 8-wave workgroup finds room on a busy CU sooner than a 16-wave one.  GS4D_BTS_THREADS=1024: the other form (experiments).
+    static const int threads = getenv("GS4D_BTS_THREADS") ? atoi(getenv("GS4D_BTS_THREADS")) : 512;
+    const uint32_t rounds = (t.rows * t.cpr + threads - 1) / threads;
+#define GS4D_BTS(R, T) k_bucket_tiles_staged<R, T><<<dim3(t.nb), dim3(T), t.counters * 4u, st>>>(t.slot_mem, t.hist, t.hist + t.hist_cap, t.rows, t.cpr, t.scap, t.bcap, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, \
                                                                                                    t.counters, t.tstart, t.tcnt, entries, t.bstat, total + TL_ABORT_WORD, t.seq, hint)
-    switch (rounds) {
-    case 0: case 1: GS4D_BTS(1); break;
-    case 2: GS4D_BTS(2); break;
-    case 3: GS4D_BTS(3); break;
-    case 4: GS4D_BTS(4); break;
-    default: return hipErrorInvalidValue;                  // run_draw does not stage such a draw
+    if (threads == 512) {
+        switch (rounds) {
+        case 0: case 1: GS4D_BTS(1, 512); break;
+        case 2: GS4D_BTS(2, 512); break;
+        case 3: GS4D_BTS(3, 512); break;
+        case 4: GS4D_BTS(4, 512); break;
+        case 5: GS4D_BTS(5, 512); break;
+        case 6: GS4D_BTS(6, 512); break;
+        case 7: case 8: GS4D_BTS(8, 512); break;
+        default: return hipErrorInvalidValue;
+        }
+    } else {
+        switch (rounds) {
+        case 0: case 1: GS4D_BTS(1, 1024); break;
+        case 2: GS4D_BTS(2, 1024); break;
+        case 3: GS4D_BTS(3, 1024); break;
+        case 4: GS4D_BTS(4, 1024); break;
+        default: return hipErrorInvalidValue;                  // run_draw does not stage such a draw
+        }
     }
 #undef GS4D_BTS
     return hipGetLastError();
