@@ -408,7 +408,7 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
         HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, F.tstate, F.epoch, a.clear, F.mem,
-                                      c->list_hint, a.keybits, recbits, L.tl.slabs, L.tl.bstat, L.tl.nb, L.tl.sstat, L.tl.rows, L.tl.cpr ? L.tl.seq : 0u, 8u * L.tl.cpr, L.tl.scap, L.tl.bcap));
+                                      c->list_hint, a.keybits, recbits, L.tl.slabs, L.tl.bstat, L.tl.nb, L.tl.sstat, L.tl.rows, L.tl.cpr ? L.tl.seq : 0u, 0xFFFFFFFFu, L.tl.scap, L.tl.bcap));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event (the compositor's first workgroup wrote them)
     return GS4D_OK;
@@ -454,14 +454,12 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
             geom = (geom ^ v) * 0x100000001b3ull;
         const_cast<DrawArgs&>(a).slot_geom = geom;
         if (c->slot_enable && c->slot_known && c->slot_geom == geom && !a.no_slots && L.tl.seg <= (uint32_t)(STAGE_R * SEG_THREADS)) {
-            // margins: a quarter on the longest run (a Poisson tail), an eighth on the fullest segment and the fullest bucket
-            uint64_t cpr = ((uint64_t)c->slot_max_run + c->slot_max_run / 4 + 4 + 7) / 8;
-            { static const char* ev = getenv("GS4D_STAGE_CPR"); if (ev && atoi(ev) >= 1) cpr = (uint64_t)atoi(ev); }      // experiment / test knob
+            // margins: an eighth on the fullest segment and on the fullest bucket (the longest run is no capacity of anything any more: statistics only)
             const uint64_t scap = ((uint64_t)c->slot_max_seg + c->slot_max_seg / 8 + 64 + 63) & ~63ull;
             const uint64_t bcap = ((uint64_t)c->slot_max_bucket + c->slot_max_bucket / 8 + 512 + 63) & ~63ull;
-            if (scap <= STAGE_MAX_SCAP && (uint64_t)L.tl.rows * cpr <= 4096 && (uint64_t)L.tl.nb * bcap < 0xFFFFFFF0ull) {      // (k_bucket_tiles_staged: up to 8 rounds of 512 chunks, or 4 of 1024)
+            if (scap <= STAGE_MAX_SCAP && bcap <= 32u * 512u && (uint64_t)L.tl.nb * bcap < 0xFFFFFFF0ull) {      // (k_bucket_tiles_staged: a thread holds at most 32 of its bucket's entries)
                 HIPCHK(c, tile_lists_reserve_slots(L.s, L.tl, (size_t)L.tl.rows * scap));
-                L.tl.cpr = (uint32_t)cpr; L.tl.scap = (uint32_t)scap; L.tl.bcap = (uint32_t)bcap;
+                L.tl.cpr = 1u; L.tl.scap = (uint32_t)scap; L.tl.bcap = (uint32_t)bcap;
                 if (++L.tl.seq == 0u) L.tl.seq = 1u;
             }
         }

@@ -168,7 +168,7 @@ struct TileLists {
     uint2* slot_mem = nullptr; size_t slot_cap = 0;           // in entries
     uint4* bstat = nullptr;                                    // [nb_cap]
     uint32_t* sstat = nullptr;                                 // [1024]
-    uint32_t cpr = 0, scap = 0, bcap = 0;                     // of the current draw when it is staged (cpr != 0): 8-entry chunks a (bucket, segment) run may have, entries a segment block holds, bucket capacity in the tile-ordered entry array
+    uint32_t cpr = 0, scap = 0, bcap = 0;                     // of the current draw when it is staged (cpr != 0: a flag): entries a segment block holds, bucket capacity in the tile-ordered entry array
     uint32_t seq = 0;                                          // sequence number of the lane's staged draws: total[TL_ABORT_WORD] == seq <=> this draw was aborted
 };
 constexpr int TL_ABORT_WORD = 9;                              // index into BinScratch::total

@@ -237,71 +237,83 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
 
 // Staged draws: no scan and no scatter kernel ran.  The projection kernel (preprocess.hip, k_project_count<.., 2>) wrote every segment's entries as
 // one dense block, bucket after bucket: bucket b's run of segment w is blocks[w * scap + offs[b][w] + k], k < hist[b][w].  This workgroup reads its
-// bucket's counts and offsets, checks what the host only guessed — at most 8 * cpr entries in a run, bcap entries in the bucket, `hint` in a
-// tile's list — and otherwise does what k_bucket_tiles does.  Chunk q of the bucket is entries [8 (q % cpr), +8) of run q / cpr; a thread
-// keeps the chunks of its ROUNDS rounds in registers between counting and placing.  The tile lists of bucket b go to entries[b * bcap ...].
-// Statistics {entries, longest run, longest list} go to bstat[b]; a bucket that does not fit stores the draw's sequence number into *abort_word
-// (every writer stores the same value).
-template <int ROUNDS, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_bucket_tiles_staged(const uint2* __restrict__ blocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t rows, uint32_t cpr, uint32_t scap,
+// bucket's counts and offsets, turns the counts into a prefix (entry i of the bucket -> run, slot), and gives every thread the same number of
+// CONSECUTIVE entries of the bucket (ceil(T / THREADS) <= KMAX, kept in registers between counting and placing): one binary search for a thread's first
+// entry, then it walks on through the runs.  (A first version gave every thread fixed 8-slot chunks of the runs — capacity for the longest run in every
+// run: 28 % of the lanes carried an entry in the LDS-atomic loops, 80 registers of entries per thread, and the longest run was one more guess that could
+// miss.)  It checks what the host only guessed — bcap entries in the bucket, `hint` in a tile's list — and otherwise does what k_bucket_tiles does.
+// The tile lists of bucket b go to entries[b * bcap ...].  Statistics {entries, longest run, longest list} go to bstat[b]; a bucket that does not fit
+// stores the draw's sequence number into *abort_word (every writer stores the same value).
+template <int KMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_bucket_tiles_staged(const uint2* __restrict__ blocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t rows, uint32_t scap,
                                                                     uint32_t bcap, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift, uint32_t nc, uint32_t* __restrict__ tstart,
                                                                     uint32_t* __restrict__ tcnt, uint2* __restrict__ entries, uint4* __restrict__ bstat, uint32_t* __restrict__ abort_word, uint32_t seq, uint32_t hint) {
     extern __shared__ uint32_t cnt[];                      // [nc]
     __shared__ uint32_t ws[THREADS / 64], wm[THREADS / 64];
-    __shared__ uint32_t rc[1024], ro[1024];                // the bucket's run counts and where each run starts (rows <= 1024: tile_lists_plan)
+    __shared__ uint32_t rp[1025], ro[1024];                // rp[w]: entries of the bucket before run w (rp[rows] = all of them); ro[w]: where run w starts in `blocks` (rows <= 1024: tile_lists_plan)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
     const uint32_t sl = (uint32_t)__ffs((int)slabs) - 1u;
     for (uint32_t k = tid; k < nc; k += THREADS) cnt[k] = 0u;
-    // ---- the bucket's counts: total, longest run ----
-    uint32_t tsum = 0, tmax = 0;
+    // ---- the bucket's counts -> prefix over the runs; total, longest run.  Thread t looks after runs [t * RPT, (t + 1) * RPT) ----
+    constexpr uint32_t RPT = 1024u / THREADS;
+    uint32_t c[RPT], tsum = 0, tmax = 0;
 #pragma unroll
-    for (int rr = 0; rr < 1024 / THREADS; ++rr) {
-        const uint32_t wseg = (uint32_t)rr * THREADS + tid;
-        const uint32_t myc = wseg < rows ? hist[(size_t)b * rows + wseg] : 0u;
-        rc[wseg] = myc;
+    for (uint32_t k = 0; k < RPT; ++k) {
+        const uint32_t wseg = tid * RPT + k;
+        c[k] = wseg < rows ? hist[(size_t)b * rows + wseg] : 0u;
         ro[wseg] = wseg < rows ? wseg * scap + offs[(size_t)b * rows + wseg] : 0u;
-        tsum += myc; tmax = max(tmax, myc);
+        tsum += c[k]; tmax = max(tmax, c[k]);
     }
+    uint32_t pinc = tsum;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { tsum += __shfl_xor(tsum, off, 64); tmax = max(tmax, (uint32_t)__shfl_xor(tmax, off, 64)); }
-    if (lane == 0u) { ws[w] = tsum; wm[w] = tmax; }
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(pinc, off, 64); if (lane >= (unsigned)off) pinc += v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tmax = max(tmax, (uint32_t)__shfl_xor(tmax, off, 64));
+    if (lane == 63u) ws[w] = pinc;
+    if (lane == 0u) wm[w] = tmax;
     __syncthreads();
-    uint32_t T = 0, maxrun = 0;
+    uint32_t T = 0, maxrun = 0, pbase = 0;
 #pragma unroll
-    for (int k = 0; k < THREADS / 64; ++k) { T += ws[k]; maxrun = max(maxrun, wm[k]); }
+    for (int k = 0; k < THREADS / 64; ++k) { if ((unsigned)k < w) pbase += ws[k]; T += ws[k]; maxrun = max(maxrun, wm[k]); }
+    {
+        uint32_t run = pbase + pinc - tsum;
+#pragma unroll
+        for (uint32_t k = 0; k < RPT; ++k) { rp[tid * RPT + k] = run; run += c[k]; }
+        if (tid == THREADS - 1u) rp[1024] = run;          // (= T; runs beyond `rows` are empty, so rp[rows..1024] == T)
+    }
     // (a segment that overflowed its block wrote no entries and raised the abort word itself; its counts are still true)
-    const bool fits = maxrun <= 8u * cpr && T <= bcap;     // uniform
+    const uint32_t per = (T + THREADS - 1u) / THREADS;     // entries per thread
+    const bool fits = T <= bcap && per <= (uint32_t)KMAX;   // uniform
     if (!fits) {
         if (tid == 0u) { bstat[b] = make_uint4(T, maxrun, 0u, 0u); *abort_word = seq; }
         return;
     }
-    __syncthreads();                                        // (ws / wm are reused below)
-    const uint32_t nchunks = rows * cpr;
+    __syncthreads();                                        // rp / ro complete; ws / wm are reused below
     auto counter_of = [&](const uint2& e) { return min(nc - 1u, ((e.y >> 24) << sl) | min(slabs - 1u, e.x >> slab_shift)); };
-    uint2 e[ROUNDS][8];
-    uint32_t ne[ROUNDS];
+    uint2 e[KMAX];
+    const uint32_t s0 = min(T, tid * per), s1 = min(T, s0 + per);
+    {
+        // the run that holds entry s0: the last w with rp[w] <= s0 among 0..1023 (empty runs share their successor's prefix: the walk below skips them)
+        uint32_t lo = 0, hi = 1024;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
-        const uint32_t q = (uint32_t)r * THREADS + tid;
-        ne[r] = 0u;
-        if (q < nchunks) {
-            const uint32_t run = q / cpr, s0 = (q - run * cpr) << 3;
-            const uint32_t c = rc[run];
-            ne[r] = c > s0 ? min(8u, c - s0) : 0u;
-            const uint2* __restrict__ p = blocks + ro[run] + s0;
+        for (int it = 0; it < 10; ++it) { const uint32_t mid = (lo + hi) >> 1; if (rp[mid] <= s0) lo = mid; else hi = mid; }
+        uint32_t run = lo, next = rp[min(run + 1u, 1024u)], first = rp[run];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) if ((uint32_t)k < ne[r]) e[r][k] = p[k];
+        for (int k = 0; k < KMAX; ++k) {
+            const uint32_t i = s0 + (uint32_t)k;
+            if (i < s1) {
+                while (i >= next) { ++run; first = next; next = rp[min(run + 1u, 1024u)]; }      // (i < T = rp[1024]: terminates)
+                e[k] = blocks[ro[run] + (i - first)];
+            }
         }
     }
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if ((uint32_t)k < ne[r]) atomicAdd(&cnt[counter_of(e[r][k])], 1u);
+    for (int k = 0; k < KMAX; ++k) if (s0 + (uint32_t)k < s1) atomicAdd(&cnt[counter_of(e[k])], 1u);
     __syncthreads();
     // exclusive scan of the nc counters, the tile table, the longest sub-list (as k_bucket_tiles)
     const uint32_t cpt = (nc + THREADS - 1u) / THREADS, q0c = tid * cpt;
     uint32_t sum = 0, mx = 0;
-    for (uint32_t k = 0; k < cpt; ++k) { const uint32_t q = q0c + k; const uint32_t c = q < nc ? cnt[q] : 0u; sum += c; mx = max(mx, c); }
+    for (uint32_t k = 0; k < cpt; ++k) { const uint32_t q = q0c + k; const uint32_t cq = q < nc ? cnt[q] : 0u; sum += cq; mx = max(mx, cq); }
     uint32_t inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off, 64); if (lane >= (unsigned)off) inc += v; }
@@ -313,27 +325,25 @@ __global__ __launch_bounds__(THREADS) void k_bucket_tiles_staged(const uint2* __
     uint32_t wbase = 0, longest = 0;
 #pragma unroll
     for (int k = 0; k < THREADS / 64; ++k) { if ((unsigned)k < w) wbase += ws[k]; longest = max(longest, wm[k]); }
-    const uint32_t lo = b * bcap;
-    uint32_t run = lo + wbase + inc - sum;
+    const uint32_t lo_e = b * bcap;
+    uint32_t runpos = lo_e + wbase + inc - sum;
     for (uint32_t k = 0; k < cpt; ++k) {
         const uint32_t q = q0c + k;
         if (q < nc) {
-            const uint32_t c = cnt[q];
-            cnt[q] = run;
+            const uint32_t cq = cnt[q];
+            cnt[q] = runpos;
             const uint32_t tile = (q >> sl) * nb + b;
-            if (tile < ntiles) { tstart[(size_t)tile * slabs + (q & (slabs - 1u))] = run; tcnt[(size_t)tile * slabs + (q & (slabs - 1u))] = c; }
-            run += c;
+            if (tile < ntiles) { tstart[(size_t)tile * slabs + (q & (slabs - 1u))] = runpos; tcnt[(size_t)tile * slabs + (q & (slabs - 1u))] = cq; }
+            runpos += cq;
         }
     }
     if (tid == 0u) { bstat[b] = make_uint4(T, maxrun, longest, 0u); if (longest > hint) *abort_word = seq; }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if ((uint32_t)k < ne[r]) {
-            const uint32_t pos = atomicAdd(&cnt[counter_of(e[r][k])], 1u);
-            entries[pos] = make_uint2(e[r][k].x, e[r][k].y & 0x00FFFFFFu);
-        }
+    for (int k = 0; k < KMAX; ++k) if (s0 + (uint32_t)k < s1) {
+        const uint32_t pos = atomicAdd(&cnt[counter_of(e[k])], 1u);
+        entries[pos] = make_uint2(e[k].x, e[k].y & 0x00FFFFFFu);
+    }
 }
 
 bool tile_lists_plan(TileLists& t, size_t ntiles, size_t nrecords, uint32_t slabs, int keybits, uint32_t key_span, size_t expect_entries) {
@@ -432,32 +442,14 @@ hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint
 }
 
 hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint2* entries, uint32_t hint) {
-    // 512 threads: the same 18 us alone as with 1024, 4 % more frames per second with the frame lanes overlapping (0.0955-0.0961 against 0.0992-0.1018 ms per
-    // frame at C2, alternating runs) — an 8-wave workgroup finds room on a busy CU sooner than a 16-wave one.  GS4D_BTS_THREADS=1024: the other form (experiments).
-    static const int threads = getenv("GS4D_BTS_THREADS") ? atoi(getenv("GS4D_BTS_THREADS")) : 512;
-    const uint32_t rounds = (t.rows * t.cpr + threads - 1) / threads;
-#define GS4D_BTS(R, T) k_bucket_tiles_staged<R, T><<<dim3(t.nb), dim3(T), t.counters * 4u, st>>>(t.slot_mem, t.hist, t.hist + t.hist_cap, t.rows, t.cpr, t.scap, t.bcap, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, \
-                                                                                                   t.counters, t.tstart, t.tcnt, entries, t.bstat, total + TL_ABORT_WORD, t.seq, hint)
-    if (threads == 512) {
-        switch (rounds) {
-        case 0: case 1: GS4D_BTS(1, 512); break;
-        case 2: GS4D_BTS(2, 512); break;
-        case 3: GS4D_BTS(3, 512); break;
-        case 4: GS4D_BTS(4, 512); break;
-        case 5: GS4D_BTS(5, 512); break;
-        case 6: GS4D_BTS(6, 512); break;
-        case 7: case 8: GS4D_BTS(8, 512); break;
-        default: return hipErrorInvalidValue;
-        }
-    } else {
-        switch (rounds) {
-        case 0: case 1: GS4D_BTS(1, 1024); break;
-        case 2: GS4D_BTS(2, 1024); break;
-        case 3: GS4D_BTS(3, 1024); break;
-        case 4: GS4D_BTS(4, 1024); break;
-        default: return hipErrorInvalidValue;                  // run_draw does not stage such a draw
-        }
-    }
+    // 512 threads: the same time alone as with 1024, 4 % more frames per second with the frame lanes overlapping (0.0955-0.0961 against 0.0992-0.1018 ms per
+    // frame at C2, alternating runs) — an 8-wave workgroup finds room on a busy CU sooner than a 16-wave one.  A thread holds up to 16 (buckets of <= 8192
+    // entries: what tile_lists_plan aims at) or 32 entries.
+#define GS4D_BTS(K) k_bucket_tiles_staged<K, 512><<<dim3(t.nb), dim3(512), t.counters * 4u, st>>>(t.slot_mem, t.hist, t.hist + t.hist_cap, t.rows, t.scap, t.bcap, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, \
+                                                                                                 t.counters, t.tstart, t.tcnt, entries, t.bstat, total + TL_ABORT_WORD, t.seq, hint)
+    if (t.bcap <= 16u * 512u) GS4D_BTS(16);
+    else if (t.bcap <= 32u * 512u) GS4D_BTS(32);
+    else return hipErrorInvalidValue;                      // run_draw does not stage such a draw
 #undef GS4D_BTS
     return hipGetLastError();
 }
