@@ -166,3 +166,32 @@ def test_quads_and_2d_draws_take_the_slotted_lists_too(gs4d, oracle, monkeypatch
     p = oracle.preprocess(oracle.MODE_3D, verts, cam["view"], proj, W, H)
     eimg = oracle.composite(p, None, oracle.MODE_3D, W, H, oracle.clear_image(W, H))
     assert np.abs(img.astype(np.float64) - eimg).max() <= TOL
+
+
+@pytest.mark.parametrize("n,W,H", [(80, 1280, 720), (37, 640, 360), (1000, 1280, 720)])
+def test_large_footprints_and_tiny_sets_are_staged_too(gs4d, oracle, monkeypatch, n, W, H):
+    """the reference's own teapot records at a close camera: footprints of tens to hundreds of tiles (the wave-cooperative branch of the placing pass,
+    runs of dozens of entries), a set smaller than one wave, and 1000 records whose 45 000 entries do not fit a segment block (such a draw is never staged:
+    its lists stay exact) — eight frames each, the later ones must equal the first (exact) one and the checker"""
+    rec = np.ascontiguousarray(oracle.golden("linear_first1000")[:n], np.float32)
+    cam = ((30.0, 45.0, 45.0), (0.0, -1.0, -1.0))
+    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, slotted=True)
+    imgs = []
+    for k in range(8):
+        frame(ctx, gs4d, bufs, n, cam, W, H, t=0.0)
+        if k in (0, 7):
+            imgs.append(ctx.read_pixels())
+    st = ctx.stats()
+    perm = ctx.read(bufs[2], np.uint32, n)
+    ctx.close()
+    assert st["slot_misses"] == 0, st
+    if n <= 100 and st["unordered_draws"] >= 8:         # (lists short enough for the unordered path and a segment that fits its block: the later frames were staged)
+        assert st["slotted_draws"] >= 3, st
+    if n == 1000:
+        assert st["slotted_draws"] == 0, st
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    view, proj = mats(gs4d, cam, W, H)
+    eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    assert np.array_equal(perm, eperm)
+    assert np.abs(imgs[1].astype(np.float64) - eimg).max() <= TOL
+    assert np.abs(eimg - oracle.CLEAR).max() > 0.05
