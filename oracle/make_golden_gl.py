@@ -172,7 +172,7 @@ def gl_lines(W, H, vp, sets):
         cp, vp_ = os.path.join(TMP, f"col{k}.bin"), os.path.join(TMP, f"verts{k}.bin")
         np.asarray(col, np.float32).tofile(cp)
         np.ascontiguousarray(verts, np.float32).tofile(vp_)
-        args += [cp, width, len(verts), vp_, int(strip)]
+        args += [cp, width, len(verts), vp_, 2 if np.asarray(verts).shape[-1] == 2 else int(strip)]
     refgl(*args)
     return np.fromfile(os.path.join(TMP, "lines.img.f32"), np.float32).reshape(H, W, 4)
 
@@ -187,6 +187,7 @@ def lines_fixture(name, cam, W, H, source):
     sets += [(np.array([[0, 0, 0], p], np.float32), c, 3.0, 0) for p, c in (([10, 0, 0], (1, 0, 0, 1)), ([0, 10, 0], (0, 1, 0, 1)), ([0, 0, 10], (0, 0, 1, 1)))]
     sets += [(np.array([[0, 0, 0], [1, 0, 0]], np.float32), (1, 1, 1, 1), 5.0, 0), (np.array([[0, 0, 0], [50, 0, 0]], np.float32), (1, 0, 0, 1), 5.0, 0)]
     sets += [(np.stack([np.array([20 * np.cos(a), 5.0 + a, 20 * np.sin(a)], np.float32) for a in np.linspace(0, 6.0, 60)]), (1.0, 0.5, 0.1, 0.8), 2.0, 1)]
+    sets += [(np.array([[-0.9, -0.8], [0.7, 0.95], [-0.5, 0.5], [0.5, 0.5]], np.float32), (0.2, 0.9, 0.3, 0.5), 3.0, 0)]       # Renderer::DrawLine(vec2, vec2, color): NDC, width 3 (Renderer.cpp:168-201)
     img = gl_lines(W, H, vp, sets)
     x0, y0, x1, y1, touched = crop_box(img, ol.CLEAR)
     arrays = {"size": np.array([W, H], np.int32), "vp": vp, "box": np.array([x0, y0, x1, y1], np.int32), "nsets": np.array([len(sets)], np.int32)}
@@ -227,6 +228,17 @@ def main():
         for c, cam in enumerate(sd.cameras(ol)):
             for k, t in enumerate(ol.golden(f"splat_draw_4d_b{blk}_times")):
                 vs_fixture(f"gl_vs_nonlinear_b{blk}_cam{c}_t{k}", "4d", rec, float(t), 0.0, cam["view"], cam["proj"], cam["W"], cam["H"], False, fixture)
+    # the other four teapot scenes of the reference (records from refgen), each from its own scene camera, at the block's own time and in its fade
+    OTHER = (("rotation_block45_first200", ((0.0, 60.0, 30.0), (0.0, -1.0, -0.5)), "Scenes.h:748-749"),
+             ("combined_block33_first200", ((50.0, 90.0, 90.0), (0.0, -1.0, -1.0)), "Scenes.h:1003-1004"),
+             ("broken_block19_first200", ((0.0, 60.0, 60.0), (0.0, -1.0, -1.0)), "Scenes.h:1941-1942"),
+             ("square_block91_first200", ((0.0, 60.0, 60.0), (0.0, -1.0, -1.0)), "Scenes.h:2192-2193"))
+    for fixture, cam, where in OTHER:
+        rec = ol.golden(fixture)
+        v, p = VP(cam, 1280, 720)
+        t0 = float(rec[0, 3])
+        for k, t in enumerate((t0, t0 + 0.6)):
+            vs_fixture(f"gl_vs_{fixture.split('_')[0]}_t{k}", "4d", rec, t, 0.0, v, p, 1280, 720, False, fixture)
     gs4d = __import__("4dgaussiansplatrendering_amd")
     pos, q, scale, rgba = scenes.cube_params(4096)
     cube = gs4d.build_records_3d(pos, q, scale, rgba)
@@ -258,6 +270,10 @@ def main():
     img_fixture("gl_img_nonlinear_b45_640_minop", "4d", nl, tm + 0.8, 0.25, cam_n[0], v, p, 640, 360, False, "nonlinear_block45_first200, uMinOpacity 0.25")
     for s, d, tag in ((1, 0x0303, "one_oneminus"), (0x0302, 1, "srcalpha_one")):      # two more pairs of DebugMenus.h:41-59's menu
         img_fixture(f"gl_img_nonlinear_b45_640_{tag}", "4d", nl, tm, 0.0, cam_n[0], v, p, 640, 360, False, "nonlinear_block45_first200", blend=(s, d), unorm16=True)
+    for fixture, cam, where in OTHER:
+        rec = ol.golden(fixture)
+        v, p = VP(cam, 640, 360)
+        img_fixture(f"gl_img_{fixture.split('_')[0]}_640", "4d", rec, float(rec[0, 3]) + 0.4, 0.0, cam[0], v, p, 640, 360, False, fixture)
     # a dense cut of the cube: long blend chains (scale x3 as in __graft_entry__.smoke)
     cube3 = gs4d.build_records_3d(pos, q, scale * 3.0, rgba)
     cam_near = ((330.0, 210.0, -110.0), cam_c[1])

@@ -32,7 +32,7 @@
 //        img16-> <out_prefix>.img.u16  : the same draw into an RGBA16 (unsigned normalised) attachment: a fixed-point framebuffer like the
 //                                        reference's window — source and result of every blend clamped to [0, 1] (OpenGL 4.4, 17.3.8), which a
 //                                        float attachment does not do — with 1.5e-5 steps instead of 1/255
-//   refgl lines <W> <H> <viewproj.bin> <out_prefix> (<color.bin> <width> <nverts> <verts.bin> <strip:0|1>)+    all sets into one frame
+//   refgl lines <W> <H> <viewproj.bin> <out_prefix> (<color.bin> <width> <nverts> <verts.bin> <strip:0|1|2>)+    all sets into one frame; strip 2 = 2D lines (vec2 NDC positions, Line2DVert/Frag)
 //   refgl sort <n> <keys.bin> <vals.bin> <out_prefix>      -> <out_prefix>.keys.u32 / .vals.u32
 #include <cmath>
 #include <cstdint>
@@ -323,25 +323,31 @@ static int cmd_lines(int argc, char** argv) {
     std::vector<uint8_t> vp = slurp(argv[4]); std::string out = argv[5];
     if (vp.size() != 64) die("lines: viewproj must be 16 floats");
     GLuint prog = link_program({ compile_file(GL_VERTEX_SHADER, "Shader/Lines/LineVert.GLSL"), compile_file(GL_FRAGMENT_SHADER, "Shader/Lines/LineFrag.GLSL") });   // Renderer.h:32-34
+    GLuint prog2d = link_program({ compile_file(GL_VERTEX_SHADER, "Shader/Lines/Line2DVert.GLSL"), compile_file(GL_FRAGMENT_SHADER, "Shader/Lines/Line2DFrag.GLSL") });   // Renderer.h:29-31
     make_target(W, H, GL_RGBA32F);
     frame_state(GL_SRC_ALPHA, GL_ONE_MINUS_SRC_ALPHA);
     for (int a = 6; a + 4 < argc; a += 5) {
         std::vector<uint8_t> col = slurp(argv[a]);
         float width = (float)atof(argv[a + 1]); long nv = atol(argv[a + 2]);
         std::vector<uint8_t> verts = slurp(argv[a + 3]); int strip = atoi(argv[a + 4]);
-        if (col.size() != 16 || verts.size() != (size_t)nv * 12) die("lines: bad input sizes");
+        const bool two_d = strip == 2;                    // strip 2: Renderer::DrawLine(vec2, vec2, color) — NDC positions, the 2D program (Renderer.cpp:168-201)
+        if (col.size() != 16 || verts.size() != (size_t)nv * (two_d ? 8 : 12)) die("lines: bad input sizes");
         // Renderer::DrawLine / DrawGrid body, Renderer.cpp:41-73 / 113-160: program, two uniforms, a fresh VBO + VAO, attribute 0 = vec3, width, draw
-        glUseProgram(prog);
-        glUniformMatrix4fv(uni(prog, "uViewProj"), 1, GL_FALSE, (const float*)vp.data());
-        const float* c = (const float*)col.data(); glUniform4f(uni(prog, "uColor"), c[0], c[1], c[2], c[3]);
+        const float* c = (const float*)col.data();
+        if (two_d) { glUseProgram(prog2d); glUniform4f(uni(prog2d, "uColor"), c[0], c[1], c[2], c[3]); }
+        else {
+            glUseProgram(prog);
+            glUniformMatrix4fv(uni(prog, "uViewProj"), 1, GL_FALSE, (const float*)vp.data());
+            glUniform4f(uni(prog, "uColor"), c[0], c[1], c[2], c[3]);
+        }
         GLuint vbo; glGenBuffers(1, &vbo); glBindBuffer(GL_ARRAY_BUFFER, vbo);
         glBufferData(GL_ARRAY_BUFFER, (GLsizeiptr)verts.size(), verts.data(), GL_STATIC_DRAW);
         GLuint vao; glGenVertexArrays(1, &vao); glBindVertexArray(vao);
-        glEnableVertexAttribArray(0); glVertexAttribPointer(0, 3, GL_FLOAT, GL_FALSE, 0, nullptr);
+        glEnableVertexAttribArray(0); glVertexAttribPointer(0, two_d ? 2 : 3, GL_FLOAT, GL_FALSE, 0, nullptr);
         glLineWidth(width);
         GLenum e = glGetError();
         if (e) fprintf(stderr, "refgl lines: glLineWidth(%g) -> 0x%x\n", width, e);
-        glDrawArrays(strip ? GL_LINE_STRIP : GL_LINES, 0, (GLsizei)nv);
+        glDrawArrays(strip == 1 ? GL_LINE_STRIP : GL_LINES, 0, (GLsizei)nv);
         glDeleteBuffers(1, &vbo);
     }
     glFinish(); GLCHK("lines");
