@@ -76,7 +76,7 @@ template <bool PREMULT_C, int PER>
 __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ proj, const uint2* __restrict__ entries, const uint32_t* __restrict__ tstart, const uint32_t* __restrict__ tcnt,
                                                      const uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, int tiles_x, int W, int H, uint32_t* __restrict__ tstate, uint32_t epoch, float4 clear,
                                                      float4* __restrict__ fb, int key_passes, int rec_passes, uint32_t slabs,
-                                                     const uint4* __restrict__ bstat, uint32_t nb, const uint32_t* __restrict__ sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap,
+                                                     const uint4* __restrict__ bstat, uint32_t nb, const uint32_t* __restrict__ sstat, uint32_t rows, uint32_t stage_seq, uint32_t rcap, uint32_t scap, uint32_t bcap,
                                                      unsigned long long* __restrict__ stamps) {
     // the sort's key plane and the blend's record staging never live at the same time: one piece of LDS serves both
     constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
@@ -94,17 +94,17 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
 #endif
     // what the list kernels found out — entries, longest list, abort flags — goes to the host from here (pinned, mapped memory behind
     // the lane's event): they are complete now, and none of them has to wait for a hand-off of its own
-    // A staged draw (slot_seq != 0, tilelist.hip) has no scan kernel that could have added anything up: its verdict is the abort word and the
+    // A staged draw (stage_seq != 0, tilelist.hip) has no scan kernel that could have added anything up: its verdict is the abort word and the
     // per-bucket statistics {entries, longest run, longest list} and per-segment entry counts, reduced here.  An exact draw reports its statistics
     // the same way (they size the blocks, runs and buckets of the staged draws that follow) beside the totals its scan kernel left.
     // Everything the tile needs before it can ask for its list is requested HERE, in one go — the verdict word, the tile's table row, its state
     // word: three independent loads, one round trip.  (Issued one behind the other's branch they were three round trips: per-tile stamps of a
     // TUNING build showed 3.9 us between a workgroup's start and its list being in order for lists of <= 64 entries — tools/v2_timeline.py.)
-    const uint32_t verdict = slot_seq ? total[TL_ABORT_WORD] : total[1];
+    const uint32_t verdict = stage_seq ? total[TL_ABORT_WORD] : total[1];
     uint32_t my_start = 0u, my_cnt = 0u;                    // lane s: sub-list s of this tile (one load for the whole table row)
     if (real && lane < slabs) { my_start = tstart[(size_t)tile * slabs + lane]; my_cnt = tcnt[(size_t)tile * slabs + lane]; }
     const uint32_t tstate_word = real ? tstate[tile] : 0u;
-    const bool aborted = slot_seq ? verdict == slot_seq : verdict != 0u;
+    const bool aborted = stage_seq ? verdict == stage_seq : verdict != 0u;
     if (blockIdx.x == 0u) {
         unsigned long long sum = 0ull; uint32_t mrun = 0u, mbucket = 0u, mlist = 0u, mseg = 0u;
         if (bstat) for (uint32_t b = lane; b < nb; b += 64u) { const uint4 v = bstat[b]; sum += v.x; mrun = max(mrun, v.y); mbucket = max(mbucket, v.x); mlist = max(mlist, v.z); }
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
         }
         if (lane == 0u) {
             total_host[6] = mrun; total_host[7] = mbucket; total_host[8] = mseg;
-            if (slot_seq) {
+            if (stage_seq) {
                 // flags: 4 = a segment, a run or a bucket did not fit what the host guessed (re-run exactly), 2 = a list longer than the compositor was launched for.
                 // (A segment that overflowed wrote no entries: the bucket statistics then count entries that are not there, and the sum is still the true total.)
                 const bool guess_ok = mrun <= rcap && mbucket <= bcap && mseg <= scap;
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
 
 template <bool PREMULT_C>
 static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int W, int H,
-                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs, const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap, unsigned long long* stamps) {
-#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap, stamps)
+                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs, const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t stage_seq, uint32_t rcap, uint32_t scap, uint32_t bcap, unsigned long long* stamps) {
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, stamps)
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
@@ -208,7 +208,7 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
 
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs,
-                               const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t slot_seq, uint32_t rcap, uint32_t scap, uint32_t bcap) {
+                               const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t stage_seq, uint32_t rcap, uint32_t scap, uint32_t bcap) {
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
@@ -226,8 +226,8 @@ hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* 
     const bool stamp_now = stampf && ++calls == stamp_call;
     if (stamp_now && (hipMalloc(&stamps, (size_t)grid.x * 48) != hipSuccess || hipMemsetAsync(stamps, 0, (size_t)grid.x * 48, st) != hipSuccess)) stamps = nullptr;
 #endif
-    const hipError_t le = premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap, stamps)
-                                    : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, slot_seq, rcap, scap, bcap, stamps);
+    const hipError_t le = premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, stamps)
+                                    : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, stamps);
 #ifdef GS4D_TUNING
     if (stamps) {
         (void)hipStreamSynchronize(st);

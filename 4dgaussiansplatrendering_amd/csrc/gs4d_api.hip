@@ -77,8 +77,8 @@ struct DrawArgs {
     // now the application may have overwritten it for a later frame.  The re-run regenerates "records in ascending (key, index)" from `ks`
     // into the lane's private index instead of reading the caller's buffer.
     bool regen_order = false;
-    bool no_slots = false;         // the re-run of a staged draw whose blocks, runs or buckets did not fit: builds its lists exactly (scan + scatter)
-    uint64_t slot_geom = 0;        // set by run_draw: the list geometry the draw's bucket statistics belong to (resolve_lane files them under it)
+    bool exact_lists = false;         // the re-run of a staged draw whose blocks, runs or buckets did not fit: builds its lists exactly (scan + scatter)
+    uint64_t stage_geom = 0;        // set by run_draw: the list geometry the draw's bucket statistics belong to (resolve_lane files them under it)
 };
 
 struct Framebuffer {
@@ -172,11 +172,11 @@ struct gs4d_ctx {
     uint32_t list_hint = 256;          // LDS list capacity the compositor is launched with (64 << k); grows on demand, validated per draw on the device
     // Staged lists (tilelist.hip): once a draw of a scene has reported its fullest segment, its longest (bucket, segment) run and its fullest bucket,
     // the draws that follow let the projection kernel write the list entries itself — one dense block per segment, sized by those statistics plus a
-    // margin — no scan and no scatter kernel.  The device checks the guess; a draw that does not fit is re-run exactly.  GS4D_SLOTTED=0 switches it
+    // margin — no scan and no scatter kernel.  The device checks the guess; a draw that does not fit is re-run exactly.  GS4D_STAGED=0 switches it
     // off (test hook).
-    bool slot_enable = true, slot_known = false;
-    uint32_t slot_max_run = 0, slot_max_bucket = 0, slot_max_seg = 0; uint64_t slot_geom = 0;
-    uint64_t stat_slotted = 0, stat_slot_misses = 0;
+    bool stage_enable = true, stage_known = false;
+    uint32_t stage_max_run = 0, stage_max_bucket = 0, stage_max_seg = 0; uint64_t stage_geom = 0;
+    uint64_t stat_staged = 0, stat_staged_misses = 0;
     uint64_t stat_v2_draws = 0, stat_longest = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
     static constexpr int PROF_FRAMES = 128;
@@ -389,10 +389,10 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
 #endif
         const uint32_t* fused_keys = nullptr;
         if (a.fuse) { Buffer* K = getbuf(c, a.fuse_keys); if (K) fused_keys = (const uint32_t*)K->d; }      // the projection wrote the keys there and nowhere else
-        if (L.tl.cpr) {
+        if (L.tl.staged) {
             // staged: the projection kernel wrote the segment blocks; one kernel turns them into tile lists and checks what the host guessed
             HIPCHK(c, launch_bucket_tiles_staged(L.s, L.tl, ntiles, L.bin.total, entries, c->list_hint));
-            c->stat_slotted++;
+            c->stat_staged++;
         } else {
             if (!skip_lists) {
             HIPCHK(c, launch_bucket_scan(L.s, L.tl, L.bin.total, L.host_total_dev, L.pair_cap));
@@ -408,7 +408,7 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
         HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, F.tstate, F.epoch, a.clear, F.mem,
-                                      c->list_hint, a.keybits, recbits, L.tl.slabs, L.tl.bstat, L.tl.nb, L.tl.sstat, L.tl.rows, L.tl.cpr ? L.tl.seq : 0u, 0xFFFFFFFFu, L.tl.scap, L.tl.bcap));
+                                      c->list_hint, a.keybits, recbits, L.tl.slabs, L.tl.bstat, L.tl.nb, L.tl.sstat, L.tl.rows, L.tl.staged ? L.tl.seq : 0u, 0xFFFFFFFFu, L.tl.scap, L.tl.bcap));
     }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event (the compositor's first workgroup wrote them)
     return GS4D_OK;
@@ -446,20 +446,20 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
     bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, c->slabs, a.keybits, a.key_span);
     if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
-    L.tl.cpr = L.tl.scap = L.tl.bcap = 0;
+    L.tl.staged = false; L.tl.scap = L.tl.bcap = 0;
     if (v2) {
         // the statistics of a draw belong to a list geometry (buckets, segments, tiles, records, shard, data buffer): another one starts from scratch
         uint64_t geom = 0xcbf29ce484222325ull;
         for (uint64_t v : { (uint64_t)L.tl.nb, (uint64_t)L.tl.rows, (uint64_t)L.tl.seg, (uint64_t)c->tiles_x, (uint64_t)c->tiles_y, (uint64_t)npre, (uint64_t)a.shard_world, (uint64_t)a.shard_rank, (uint64_t)a.data })
             geom = (geom ^ v) * 0x100000001b3ull;
-        const_cast<DrawArgs&>(a).slot_geom = geom;
-        if (c->slot_enable && c->slot_known && c->slot_geom == geom && !a.no_slots && L.tl.seg <= (uint32_t)(STAGE_R * SEG_THREADS)) {
+        const_cast<DrawArgs&>(a).stage_geom = geom;
+        if (c->stage_enable && c->stage_known && c->stage_geom == geom && !a.exact_lists && L.tl.seg <= (uint32_t)(STAGE_R * SEG_THREADS)) {
             // margins: an eighth on the fullest segment and on the fullest bucket (the longest run is no capacity of anything any more: statistics only)
-            const uint64_t scap = ((uint64_t)c->slot_max_seg + c->slot_max_seg / 8 + 64 + 63) & ~63ull;
-            const uint64_t bcap = ((uint64_t)c->slot_max_bucket + c->slot_max_bucket / 8 + 512 + 63) & ~63ull;
+            const uint64_t scap = ((uint64_t)c->stage_max_seg + c->stage_max_seg / 8 + 64 + 63) & ~63ull;
+            const uint64_t bcap = ((uint64_t)c->stage_max_bucket + c->stage_max_bucket / 8 + 512 + 63) & ~63ull;
             if (scap <= STAGE_MAX_SCAP && bcap <= 32u * 512u && (uint64_t)L.tl.nb * bcap < 0xFFFFFFF0ull) {      // (k_bucket_tiles_staged: a thread holds at most 32 of its bucket's entries)
-                HIPCHK(c, tile_lists_reserve_slots(L.s, L.tl, (size_t)L.tl.rows * scap));
-                L.tl.cpr = 1u; L.tl.scap = (uint32_t)scap; L.tl.bcap = (uint32_t)bcap;
+                HIPCHK(c, tile_lists_reserve_blocks(L.s, L.tl, (size_t)L.tl.rows * scap));
+                L.tl.staged = true; L.tl.scap = (uint32_t)scap; L.tl.bcap = (uint32_t)bcap;
                 if (++L.tl.seq == 0u) L.tl.seq = 1u;
             }
         }
@@ -492,10 +492,10 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
         if (ob && !v2) { int rc = lane_access(c, *ob, false); if (rc) return rc; ob->rd_mask |= 1u << a.lane; }
         {
             StageTimer t(c, GS4D_T_PREPROCESS);
-            const PreOut po = { L.proj, (v2 && L.tl.cpr) ? nullptr : L.trects };
+            const PreOut po = { L.proj, (v2 && L.tl.staged) ? nullptr : L.trects };
             L.trects_in_order = false;
             TileCount tc;
-            if (v2 && L.tl.cpr) { tc.stage_out = L.tl.slot_mem; tc.scap = L.tl.scap; tc.offs = L.tl.hist + L.tl.hist_cap; tc.abort_word = L.bin.total + TL_ABORT_WORD; tc.seq = L.tl.seq; }
+            if (v2 && L.tl.staged) { tc.stage_out = L.tl.blocks; tc.scap = L.tl.scap; tc.offs = L.tl.hist + L.tl.hist_cap; tc.abort_word = L.bin.total + TL_ABORT_WORD; tc.seq = L.tl.seq; }
             if (v2) { tc.sstat = L.tl.sstat; tc.hist = L.tl.hist; tc.skey = L.tl.skey; tc.nb = L.tl.nb; tc.seg = L.tl.seg; tc.rows = L.tl.rows; tc.tiles_x = c->tiles_x; tc.shard_rank = a.shard_rank; tc.shard_world = a.shard_world; tc.ks = a.ks; }
             if (a.fuse) {
                 tc.ks = a.ks;
@@ -548,7 +548,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     }
     size_t want = a.instances * 2 + 65536;
     if (want < c->stat_entries + c->stat_entries / 2) want = c->stat_entries + c->stat_entries / 2;
-    if (v2 && L.tl.cpr && want < (size_t)L.tl.nb * L.tl.bcap) want = (size_t)L.tl.nb * L.tl.bcap;      // staged: the tile-ordered array holds a region of bcap entries per bucket
+    if (v2 && L.tl.staged && want < (size_t)L.tl.nb * L.tl.bcap) want = (size_t)L.tl.nb * L.tl.bcap;      // staged: the tile-ordered array holds a region of bcap entries per bucket
     if (L.pair_cap < want) { int rc = ensure_pairs(c, L, want); if (rc) return rc; }
     if (v2) {
         int rc = enqueue_raster_v2(c, L, F, a, npre, premult);
@@ -582,8 +582,8 @@ int resolve_lane(gs4d_ctx* c, int li) {
         const uint64_t total = (uint64_t)L.host_total[2] | ((uint64_t)L.host_total[3] << 32);
         const uint32_t flags = L.host_total[1];
         if (L.pending_args.v2 && !(flags & 1u)) {
-            // longest (bucket, segment) run and fullest bucket of this draw: what sizes the slotted runs of the draws that follow
-            c->slot_max_run = L.host_total[6]; c->slot_max_bucket = L.host_total[7]; c->slot_max_seg = L.host_total[8]; c->slot_geom = L.pending_args.slot_geom; c->slot_known = true;
+            // longest (bucket, segment) run and fullest bucket of this draw: what sizes the staged blocks of the draws that follow
+            c->stage_max_run = L.host_total[6]; c->stage_max_bucket = L.host_total[7]; c->stage_max_seg = L.host_total[8]; c->stage_geom = L.pending_args.stage_geom; c->stage_known = true;
         }
         if (L.pending_args.v2) {
             c->stat_longest = L.host_total[5];
@@ -596,7 +596,7 @@ int resolve_lane(gs4d_ctx* c, int li) {
         if (discarded) c->stat_aborted_discarded++; else c->stat_reruns++;
         c->stat_entries = total;
         const bool was_v2 = L.pending_args.v2;     // an unordered draw kept no copy of its sort index: whatever path the re-run takes, it starts from the projection
-        if (L.pending_args.v2 && (flags & 4u)) { L.pending_args.no_slots = true; c->stat_slot_misses++; }      // a run or a bucket did not fit the guess: exact lists this time
+        if (L.pending_args.v2 && (flags & 4u)) { L.pending_args.exact_lists = true; c->stat_staged_misses++; }      // a run or a bucket did not fit the guess: exact lists this time
         if (L.pending_args.v2 && (flags & 2u)) {
             // A (sub-)list longer than the compositing wave was launched for.  What it can hold is a launch parameter (64 entries per lane
             // register: v2_list_capacity) that costs registers and LDS.  Up to V2_MAX_LIST entries: a capacity that fits.  Longer: this is a
@@ -772,7 +772,7 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if (const char* ev = getenv("GS4D_FUSE_KEYGEN")) c->defer_order = atoi(ev) != 0;                                       // test hook: 0 = launch key generation and sort at once
     if (const char* ev = getenv("GS4D_DRAW_PATH")) { if (!strcmp(ev, "ordered")) c->path_pref = 1; }
     if (const char* ev = getenv("GS4D_RENAME")) c->rename_storage = atoi(ev) != 0;
-    if (const char* ev = getenv("GS4D_SLOTTED")) c->slot_enable = atoi(ev) != 0;                                          // test hook: 0 = every unordered draw builds its lists exactly (scan + scatter)
+    if (const char* ev = getenv("GS4D_STAGED")) c->stage_enable = atoi(ev) != 0;                                          // test hook: 0 = every unordered draw builds its lists exactly (scan + scatter)
     if (const char* ev = getenv("GS4D_SLABS")) { const int v = atoi(ev); if (v >= 1 && v <= (int)V2_MAX_SLABS) { c->slabs = 1; while ((int)c->slabs < v) c->slabs *= 2u; } }      // test hook: depth slabs (a power of two)                         // test hook: instance-ordered tile lists for every draw
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
     if ((e = create_lane_streams(c)) != hipSuccess) return bail(hipfail(c, e, "hipStreamCreate"));
@@ -1475,7 +1475,7 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     if (!c || !stats) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    stats[0] = (c->stat_entries & 0xFFFFFFFFull) | (c->stat_slotted << 32); stats[1] = ((uint64_t)lane(c).pair_cap & 0xFFFFFFFFFFull) | (c->stat_slot_misses << 40); stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y | (c->stat_shadow_bytes << 32);
+    stats[0] = (c->stat_entries & 0xFFFFFFFFull) | (c->stat_staged << 32); stats[1] = ((uint64_t)lane(c).pair_cap & 0xFFFFFFFFFFull) | (c->stat_staged_misses << 40); stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y | (c->stat_shadow_bytes << 32);
     stats[4] = (c->stat_depth_passes & 0xFFFFFFFFull) | (c->stat_streams_rejected << 32); stats[5] = (c->stat_tile_passes & 0xFFFFFFFFull) | (c->stat_renamed << 32); stats[6] = (uint64_t)(c->nlanes & 0xFFFF) | (c->stat_lanes_sharing << 16) | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }

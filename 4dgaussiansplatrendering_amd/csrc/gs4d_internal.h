@@ -165,10 +165,10 @@ struct TileLists {
     // staged lists: segment blocks [rows][scap] entries; per-bucket statistics {entries, longest run, longest list, 0} written by k_bucket_tiles_staged
     // (staged draws) or k_bucket_scan (exact draws), per-segment entry counts written by the projection kernel; the compositing kernel's first
     // workgroup reduces both for the host
-    uint2* slot_mem = nullptr; size_t slot_cap = 0;           // in entries
+    uint2* blocks = nullptr; size_t blocks_cap = 0;           // in entries
     uint4* bstat = nullptr;                                    // [nb_cap]
     uint32_t* sstat = nullptr;                                 // [1024]
-    uint32_t cpr = 0, scap = 0, bcap = 0;                     // of the current draw when it is staged (cpr != 0: a flag): entries a segment block holds, bucket capacity in the tile-ordered entry array
+    bool staged = false; uint32_t scap = 0, bcap = 0;         // the current draw is staged; entries a segment block holds, bucket capacity in the tile-ordered entry array
     uint32_t seq = 0;                                          // sequence number of the lane's staged draws: total[TL_ABORT_WORD] == seq <=> this draw was aborted
 };
 constexpr int TL_ABORT_WORD = 9;                              // index into BinScratch::total
@@ -183,15 +183,15 @@ hipError_t launch_bucket_scan(hipStream_t st, TileLists& t, uint32_t* total, uin
 // skey == nullptr: the blend keys the projection left in t.skey; else an array of key bit patterns from which skey_bias is still to be subtracted (the caller's key buffer of a fused draw)
 hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint32_t* trects, const float4* proj, const uint32_t* skey, uint32_t skey_bias, size_t nrecords, const uint32_t* total, uint2* tmp, int tiles_x, int shard_rank, int shard_world);
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint);
-// staged draws: the segment blocks the projection kernel wrote (t.slot_mem, t.scap) -> tile lists at entries[b * t.bcap ...]; per-bucket statistics into t.bstat;
+// staged draws: the segment blocks the projection kernel wrote (t.blocks, t.scap) -> tile lists at entries[b * t.bcap ...]; per-bucket statistics into t.bstat;
 // total[TL_ABORT_WORD] = t.seq when a run, a bucket or a list does not fit
 hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint2* entries, uint32_t hint);
-hipError_t tile_lists_reserve_slots(hipStream_t st, TileLists& t, size_t entries);
-// bstat / nb, sstat / rows: per-bucket and per-segment statistics for the host report; slot_seq != 0: a staged draw (aborted <=> total[TL_ABORT_WORD] == slot_seq,
-// the entry total is the sum of the statistics); rcap / scap / bcap: what the host guessed for it (longest run, fullest segment, fullest bucket)
+hipError_t tile_lists_reserve_blocks(hipStream_t st, TileLists& t, size_t entries);
+// bstat / nb, sstat / rows: per-bucket and per-segment statistics for the host report; stage_seq != 0: a staged draw (aborted <=> total[TL_ABORT_WORD] == stage_seq,
+// the entry total is the sum of the statistics); rcap / scap / bcap: what the host guessed for it (longest run: no limit any more, 0xFFFFFFFF; fullest segment; fullest bucket)
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs,
-                               const uint4* bstat = nullptr, uint32_t nb = 0, const uint32_t* sstat = nullptr, uint32_t rows = 0, uint32_t slot_seq = 0, uint32_t rcap = 0, uint32_t scap = 0, uint32_t bcap = 0);
+                               const uint4* bstat = nullptr, uint32_t nb = 0, const uint32_t* sstat = nullptr, uint32_t rows = 0, uint32_t stage_seq = 0, uint32_t rcap = 0, uint32_t scap = 0, uint32_t bcap = 0);
 
 #ifdef __HIPCC__
 // tiles touched by a pixel rectangle (x0|y0<<16, x1|y1<<16; x0 > x1: none), restricted to the tile rows ty % world == rank

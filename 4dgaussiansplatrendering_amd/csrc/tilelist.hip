@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_bucket_scan(const uint32_t* __restrict_
             carry += __shfl(inc, 63, 64);
         }
         if (lane == 0) __hip_atomic_store(btot + b, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // what a later draw of this scene needs to size its slotted runs (the compositing kernel's first workgroup reduces these for the host)
+        // what a later draw of this scene needs to size its staged blocks (the compositing kernel's first workgroup reduces these for the host)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) mxr = max(mxr, (uint32_t)__shfl_xor(mxr, off, 64));
         if (lane == 0) bstat[b] = make_uint4(carry, mxr, 0u, 0u);
@@ -408,18 +408,18 @@ hipError_t tile_lists_reserve(hipStream_t st, TileLists& t, size_t ntiles, size_
     return hipSuccess;
 }
 
-hipError_t tile_lists_reserve_slots(hipStream_t st, TileLists& t, size_t entries) {
-    if (t.slot_cap >= entries) return hipSuccess;
-    if (t.slot_mem) { (void)hipStreamSynchronize(st); (void)hipFree(t.slot_mem); }
-    t.slot_mem = nullptr; t.slot_cap = 0;
-    hipError_t e = hipMalloc(&t.slot_mem, entries * 8);
+hipError_t tile_lists_reserve_blocks(hipStream_t st, TileLists& t, size_t entries) {
+    if (t.blocks_cap >= entries) return hipSuccess;
+    if (t.blocks) { (void)hipStreamSynchronize(st); (void)hipFree(t.blocks); }
+    t.blocks = nullptr; t.blocks_cap = 0;
+    hipError_t e = hipMalloc(&t.blocks, entries * 8);
     if (e != hipSuccess) return e;
-    t.slot_cap = entries;
+    t.blocks_cap = entries;
     return hipSuccess;
 }
 
 void tile_lists_free(TileLists& t) {
-    if (t.slot_mem) (void)hipFree(t.slot_mem);
+    if (t.blocks) (void)hipFree(t.blocks);
     if (t.hist) (void)hipFree(t.hist);
     if (t.bbase) (void)hipFree(t.bbase);
     if (t.skey) (void)hipFree(t.skey);
@@ -445,7 +445,7 @@ hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntile
     // 512 threads: the same time alone as with 1024, 4 % more frames per second with the frame lanes overlapping (0.0955-0.0961 against 0.0992-0.1018 ms per
     // frame at C2, alternating runs) — an 8-wave workgroup finds room on a busy CU sooner than a 16-wave one.  A thread holds up to 16 (buckets of <= 8192
     // entries: what tile_lists_plan aims at) or 32 entries.
-#define GS4D_BTS(K) k_bucket_tiles_staged<K, 512><<<dim3(t.nb), dim3(512), t.counters * 4u, st>>>(t.slot_mem, t.hist, t.hist + t.hist_cap, t.rows, t.scap, t.bcap, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, \
+#define GS4D_BTS(K) k_bucket_tiles_staged<K, 512><<<dim3(t.nb), dim3(512), t.counters * 4u, st>>>(t.blocks, t.hist, t.hist + t.hist_cap, t.rows, t.scap, t.bcap, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, \
                                                                                                  t.counters, t.tstart, t.tcnt, entries, t.bstat, total + TL_ABORT_WORD, t.seq, hint)
     if (t.bcap <= 16u * 512u) GS4D_BTS(16);
     else if (t.bcap <= 32u * 512u) GS4D_BTS(32);

@@ -338,7 +338,7 @@ def single_gpu(args, gs4d, scenes, device):
     def side_block(r, o, workload, nn, ptag):
         st_ = r["stats"]
         return {"workload": workload, "splats": nn, "ms_per_step": r["ms_per_step"], "value": r["value"], "unit": "splats/s", "windows_ms_per_step": r["windows_ms_per_step"],
-                "tile_list_entries": st_["entries"], "longest_tile_list": st_["longest_list"], "unordered_draws": st_["unordered_draws"], "staged_list_draws": st_["slotted_draws"],
+                "tile_list_entries": st_["entries"], "longest_tile_list": st_["longest_list"], "unordered_draws": st_["unordered_draws"], "staged_list_draws": st_["staged_draws"],
                 "depth_sort_passes": st_["depth_sort_passes"], "record_bytes_read_by_projection": st_["record_read_bytes"],
                 "aborted_frames_in_timed_windows": r["aborted_in_timed_windows"], "timed_window_attempts": r["timed_window_attempts"],
                 "latency_ms_one_lane": round(o["ms_per_step"], 5) if o else None,
@@ -359,7 +359,7 @@ def single_gpu(args, gs4d, scenes, device):
         "config": {"workload": (f"{n:,} 4D splats of BASELINE.json configs[3]'s set at t = 25, single 1080p frame, one GPU" if args.four_d else
                                 f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else "")),
                    "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": 1, "frame_lanes": st["lanes"],
-                   "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "staged_list_draws": st["slotted_draws"], "overflow_reruns": st["reruns"],
+                   "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "staged_list_draws": st["staged_draws"], "overflow_reruns": st["reruns"],
                    "depth_sort_passes": st["depth_sort_passes"], "record_bytes_read_by_projection": st["record_read_bytes"],
                    "aborted_frames_in_timed_windows": res["aborted_in_timed_windows"], "key_index_buffer_pairs": kb, "lane_streams_rejected_at_create": st["lane_streams_rejected"], "lanes_sharing_a_hardware_queue": st["lanes_sharing_a_queue"]},
         "one_key_index_pair": one_pair,

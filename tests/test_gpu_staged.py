@@ -2,8 +2,8 @@
 reported its fullest segment, its longest (bucket, segment) run and its fullest bucket, the following draws let the projection kernel count, scan
 and place its segment's list entries in LDS and write them out as one dense block — no scan and no scatter kernel.  The capacities are guesses
 (statistics plus a margin) that the device checks; a draw that does not fit is re-run exactly.  The picture must not depend on which way the lists
-were built: the compositor orders every list by (key, record).  ("slotted_draws" / "slot_misses" in gs4d_get_stats count the staged draws and
-the guesses that failed; GS4D_SLOTTED=0 switches the staging off.)
+were built: the compositor orders every list by (key, record).  ("staged_draws" / "staged_misses" in gs4d_get_stats count the staged draws and
+the guesses that failed; GS4D_STAGED=0 switches the staging off.)
 
 Reference path: Scenes.h:312-339 (key loop -> sort -> Draw); checker: oracle/gs4d_oracle.cpp.  Bar: image L-infinity <= 1e-4 against the
 checker, bit-identical between the two ways of building the lists, permutation bit-exact.
@@ -39,11 +39,11 @@ def frame(ctx, gs4d, bufs, n, cam, W, H, t=0.0, sort=True):
     ctx.draw_instanced(n)
 
 
-def make_ctx(gs4d, W, H, rec, monkeypatch, slotted=True, lanes=None):
-    if slotted:
-        monkeypatch.delenv("GS4D_SLOTTED", raising=False)
+def make_ctx(gs4d, W, H, rec, monkeypatch, staged=True, lanes=None):
+    if staged:
+        monkeypatch.delenv("GS4D_STAGED", raising=False)
     else:
-        monkeypatch.setenv("GS4D_SLOTTED", "0")
+        monkeypatch.setenv("GS4D_STAGED", "0")
     if lanes:
         monkeypatch.setenv("GS4D_LANES", str(lanes))
     ctx = gs4d.Context(W, H)
@@ -53,26 +53,26 @@ def make_ctx(gs4d, W, H, rec, monkeypatch, slotted=True, lanes=None):
 
 
 @pytest.mark.parametrize("sort", [True, False])
-def test_slotted_frames_equal_exact_frames(gs4d, oracle, monkeypatch, sort):
+def test_staged_frames_equal_exact_frames(gs4d, oracle, monkeypatch, sort):
     n, W, H = 200_000, 960, 540
     pos, q, scale, rgba = scenes.cube_params(n)
     rec = gs4d.build_records_3d(pos, q, scale * 2.0, rgba)
     cam = scenes.CAM_CUBE
-    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, slotted=True)
+    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, staged=True)
     for _ in range(10):
         frame(ctx, gs4d, bufs, n, cam, W, H, sort=sort)
     img = ctx.read_pixels()
     perm = ctx.read(bufs[2], np.uint32, n) if sort else None
     st = ctx.stats()
     ctx.close()
-    assert st["slotted_draws"] >= 4 and st["slot_misses"] == 0 and st["reruns"] == 0, st
-    ctx2, bufs2 = make_ctx(gs4d, W, H, rec, monkeypatch, slotted=False)
+    assert st["staged_draws"] >= 4 and st["staged_misses"] == 0 and st["reruns"] == 0, st
+    ctx2, bufs2 = make_ctx(gs4d, W, H, rec, monkeypatch, staged=False)
     for _ in range(6):
         frame(ctx2, gs4d, bufs2, n, cam, W, H, sort=sort)
     img2 = ctx2.read_pixels()
     st2 = ctx2.stats()
     ctx2.close()
-    assert st2["slotted_draws"] == 0
+    assert st2["staged_draws"] == 0
     assert np.array_equal(img.view(np.uint32), img2.view(np.uint32)), "the picture depends on how the tile lists were built"
     view, proj = mats(gs4d, cam, W, H)
     if sort:
@@ -86,45 +86,45 @@ def test_slotted_frames_equal_exact_frames(gs4d, oracle, monkeypatch, sort):
 
 
 def test_a_guess_that_does_not_fit_is_rerun_exactly(gs4d, oracle, monkeypatch):
-    """far camera (short runs) for a few frames, then a jump into the cube: runs and buckets grow several times over — the slotted draw aborts on
-    the device, is re-run with exact lists, and the frames after it are slotted again with the new sizes"""
+    """far camera (short runs) for a few frames, then a jump into the cube: runs and buckets grow several times over — the staged draw aborts on
+    the device, is re-run with exact lists, and the frames after it are staged again with the new sizes"""
     n, W, H = 150_000, 800, 448
     pos, q, scale, rgba = scenes.cube_params(n, seed=7)
     rec = gs4d.build_records_3d(pos, q, scale * 2.0, rgba)
     far = ((1400.0, 900.0, -500.0), scenes.CAM_CUBE[1])
     near = ((330.0, 210.0, -110.0), scenes.CAM_CUBE[1])
-    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, slotted=True)
+    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, staged=True)
     for _ in range(8):
         frame(ctx, gs4d, bufs, n, far, W, H)
     ctx.finish()
     s0 = ctx.stats()
-    assert s0["slotted_draws"] >= 3 and s0["slot_misses"] == 0, s0
+    assert s0["staged_draws"] >= 3 and s0["staged_misses"] == 0, s0
     frame(ctx, gs4d, bufs, n, near, W, H)
     img = ctx.read_pixels()
     perm = ctx.read(bufs[2], np.uint32, n)
     s1 = ctx.stats()
-    assert s1["slot_misses"] >= 1 and s1["reruns"] >= 1, s1
+    assert s1["staged_misses"] >= 1 and s1["reruns"] >= 1, s1
     view, proj = mats(gs4d, near, W, H)
     eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, near[0], view, proj, W, H)
     assert np.array_equal(perm, eperm)
     assert np.abs(img.astype(np.float64) - eimg).max() <= TOL
-    # the next frames of the near camera: slotted again, no further miss, same picture
+    # the next frames of the near camera: staged again, no further miss, same picture
     for _ in range(8):
         frame(ctx, gs4d, bufs, n, near, W, H)
     img2 = ctx.read_pixels()
     s2 = ctx.stats()
     ctx.close()
-    assert s2["slotted_draws"] > s1["slotted_draws"], (s1, s2)
-    assert s2["slot_misses"] <= s1["slot_misses"] + 3            # (the frames already in flight on the other lanes when the first miss was found)
+    assert s2["staged_draws"] > s1["staged_draws"], (s1, s2)
+    assert s2["staged_misses"] <= s1["staged_misses"] + 3            # (the frames already in flight on the other lanes when the first miss was found)
     assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
 
 
 def test_a_moving_camera_and_time_stay_correct(gs4d, oracle, monkeypatch):
-    """a 4D set under a time and camera sweep: every frame read back and compared with the checker, slotted or not"""
+    """a 4D set under a time and camera sweep: every frame read back and compared with the checker, staged or not"""
     n, W, H = 60_000, 640, 360
     p4, q4, s4, life, fade, vel, col4 = scenes.cube_params_4d(n)
     rec = gs4d.build_records_4d(p4, q4, s4 * 2.0, life * 8.0, fade, vel, col4)
-    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, slotted=True)
+    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, staged=True)
     worst = 0.0
     for k in range(12):
         ang = 0.05 * k
@@ -140,17 +140,17 @@ def test_a_moving_camera_and_time_stay_correct(gs4d, oracle, monkeypatch):
     st = ctx.stats()
     ctx.close()
     assert worst <= TOL, worst
-    assert st["slotted_draws"] >= 3, st
+    assert st["staged_draws"] >= 3, st
 
 
-def test_quads_and_2d_draws_take_the_slotted_lists_too(gs4d, oracle, monkeypatch):
+def test_quads_and_2d_draws_take_the_staged_lists_too(gs4d, oracle, monkeypatch):
     W, H = 640, 360
     import splat_draw_cases as sd
     cam = sd.cameras(oracle)[0]
     verts = sd.verts72(oracle.golden("splat_draw_3d_in"))
     nq = verts.shape[0]
     proj = gs4d.perspective(scenes.FOV, W, H, scenes.ZNEAR, scenes.ZFAR)
-    monkeypatch.delenv("GS4D_SLOTTED", raising=False)
+    monkeypatch.delenv("GS4D_STAGED", raising=False)
     ctx = gs4d.Context(W, H)
     ctx.set_clear_color(gs4d.CLEAR_COLOR)
     vb = ctx.buffer(verts)
@@ -162,7 +162,7 @@ def test_quads_and_2d_draws_take_the_slotted_lists_too(gs4d, oracle, monkeypatch
     img = ctx.read_pixels()
     st = ctx.stats()
     ctx.close()
-    assert st["slotted_draws"] >= 3 and st["slot_misses"] == 0, st
+    assert st["staged_draws"] >= 3 and st["staged_misses"] == 0, st
     p = oracle.preprocess(oracle.MODE_3D, verts, cam["view"], proj, W, H)
     eimg = oracle.composite(p, None, oracle.MODE_3D, W, H, oracle.clear_image(W, H))
     assert np.abs(img.astype(np.float64) - eimg).max() <= TOL
@@ -175,7 +175,7 @@ def test_large_footprints_and_tiny_sets_are_staged_too(gs4d, oracle, monkeypatch
     its lists stay exact) — eight frames each, the later ones must equal the first (exact) one and the checker"""
     rec = np.ascontiguousarray(oracle.golden("linear_first1000")[:n], np.float32)
     cam = ((30.0, 45.0, 45.0), (0.0, -1.0, -1.0))
-    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, slotted=True)
+    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, staged=True)
     imgs = []
     for k in range(8):
         frame(ctx, gs4d, bufs, n, cam, W, H, t=0.0)
@@ -184,11 +184,11 @@ def test_large_footprints_and_tiny_sets_are_staged_too(gs4d, oracle, monkeypatch
     st = ctx.stats()
     perm = ctx.read(bufs[2], np.uint32, n)
     ctx.close()
-    assert st["slot_misses"] == 0, st
+    assert st["staged_misses"] == 0, st
     if n <= 100 and st["unordered_draws"] >= 8:         # (lists short enough for the unordered path and a segment that fits its block: the later frames were staged)
-        assert st["slotted_draws"] >= 3, st
+        assert st["staged_draws"] >= 3, st
     if n == 1000:
-        assert st["slotted_draws"] == 0, st
+        assert st["staged_draws"] == 0, st
     assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
     view, proj = mats(gs4d, cam, W, H)
     eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
