@@ -492,7 +492,7 @@ class Context:
     def stats(self):
         st = np.zeros(8, np.uint64)
         self._chk(_lib.gs4d_get_stats(self._h, _ptr(st)))
-        return {"entries": int(st[0]) & 0xFFFFFFFF, "staged_draws": int(st[0]) >> 32, "capacity": int(st[1]) & 0xFFFFFFFFFF, "staged_misses": int(st[1]) >> 40, "reruns": int(st[2]) & 0xFFFFFFFF, "aborted_discarded": int(st[2]) >> 32, "tiles": int(st[3]) & 0xFFFFFFFF, "record_read_bytes": int(st[3]) >> 32,
+        return {"entries": int(st[0]) & 0xFFFFFFFF, "staged_draws": int(st[0]) >> 32, "capacity": int(st[1]) & 0xFFFFFFFFFF, "staged_misses": int(st[1]) >> 40, "reruns": int(st[2]) & 0xFFFFFFFF, "aborted_discarded": int(st[2]) >> 32, "tiles": int(st[3]) & 0xFFFFFFFF, "record_read_bytes": (int(st[3]) >> 32) & 0xFF, "composited_tiles": int(st[3]) >> 40,
                 "depth_sort_passes": int(st[4]) & 0xFFFFFFFF, "lane_streams_rejected": int(st[4]) >> 32, "tile_sort_passes": int(st[5]) & 0xFFFFFFFF, "renamed_keygens": int(st[5]) >> 32, "lanes": int(st[6]) & 0xFFFF, "lanes_sharing_a_queue": (int(st[6]) >> 16) & 0xFFFF, "fused_keygen_draws": int(st[6]) >> 32,
                 "unordered_draws": int(st[7]) & 0xFFFFFFFF, "longest_list": int(st[7]) >> 32}
 

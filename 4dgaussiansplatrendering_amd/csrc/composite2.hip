@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
                                                      const uint32_t* __restrict__ total, uint32_t* __restrict__ total_host, int tiles_x, int W, int H, uint32_t* __restrict__ tstate, uint32_t epoch, float4 clear,
                                                      float4* __restrict__ fb, int key_passes, int rec_passes, uint32_t slabs,
                                                      const uint4* __restrict__ bstat, uint32_t nb, const uint32_t* __restrict__ sstat, uint32_t rows, uint32_t stage_seq, uint32_t rcap, uint32_t scap, uint32_t bcap,
-                                                     unsigned long long* __restrict__ stamps) {
+                                                     TileBox box, uint32_t box_blocks, unsigned long long* __restrict__ stamps) {
     // the sort's key plane and the blend's record staging never live at the same time: one piece of LDS serves both
     constexpr int SHARED_WORDS = 64 * PER > 64 * 3 * 4 ? 64 * PER : 64 * 3 * 4;
     __shared__ __attribute__((aligned(16))) uint32_t sh_a[SHARED_WORDS];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     float4* stage = reinterpret_cast<float4*>(sh_a);
     uint32_t* ek = sh_a;
     uint32_t tile;
-    const bool real = composite_tile(blockIdx.x, tiles_x, (H + TILE - 1) / TILE, tile);     // false: padding of the XCD-aware grid
+    const bool real = composite_tile(blockIdx.x, tiles_x, box, tile);     // false: padding of the XCD-aware grid
     const uint32_t lane = threadIdx.x;
 #ifdef GS4D_TUNING
     const unsigned long long st0 = wall_clock64(); unsigned long long st1 = 0, st2 = 0; uint32_t stE = 0;      // per-tile stamps (100 MHz): start, list ordered, (end), entries
@@ -106,20 +106,23 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
     const uint32_t tstate_word = real ? tstate[tile] : 0u;
     const bool aborted = stage_seq ? verdict == stage_seq : verdict != 0u;
     if (blockIdx.x == 0u) {
-        unsigned long long sum = 0ull; uint32_t mrun = 0u, mbucket = 0u, mlist = 0u, mseg = 0u;
-        if (bstat) for (uint32_t b = lane; b < nb; b += 64u) { const uint4 v = bstat[b]; sum += v.x; mrun = max(mrun, v.y); mbucket = max(mbucket, v.x); mlist = max(mlist, v.z); }
+        unsigned long long sum = 0ull; uint32_t mrun = 0u, mbucket = 0u, mlist = 0u, mseg = 0u, used = BOX_EMPTY;
+        if (bstat) for (uint32_t b = lane; b < nb; b += 64u) { const uint4 v = bstat[b]; sum += v.x; mrun = max(mrun, v.y); mbucket = max(mbucket, v.x); mlist = max(mlist, v.z); used = box_join(used, v.w); }
         if (sstat) for (uint32_t w = lane; w < rows; w += 64u) mseg = max(mseg, sstat[w]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             sum += __shfl_xor(sum, off, 64); mrun = max(mrun, (uint32_t)__shfl_xor(mrun, off, 64));
             mbucket = max(mbucket, (uint32_t)__shfl_xor(mbucket, off, 64)); mlist = max(mlist, (uint32_t)__shfl_xor(mlist, off, 64)); mseg = max(mseg, (uint32_t)__shfl_xor(mseg, off, 64));
+            used = box_join(used, (uint32_t)__shfl_xor((int)used, off, 64));
         }
         if (lane == 0u) {
             total_host[6] = mrun; total_host[7] = mbucket; total_host[8] = mseg;
+            total_host[9] = stage_seq ? used : BOX_NONE;         // the blocks of tiles that hold entries (staged draws: k_bucket_tiles_staged knows; BOX_EMPTY: none)
             if (stage_seq) {
-                // flags: 4 = a segment, a run or a bucket did not fit what the host guessed (re-run exactly), 2 = a list longer than the compositor was launched for.
+                // flags: 4 = a segment, a run or a bucket did not fit what the host guessed, or an entry lies outside the launch box (re-run exactly), 2 = a list longer than the compositor was launched for.
                 // (A segment that overflowed wrote no entries: the bucket statistics then count entries that are not there, and the sum is still the true total.)
-                const bool guess_ok = mrun <= rcap && mbucket <= bcap && mseg <= scap;
+                const bool in_box = used == BOX_EMPTY || (box_holds(box_blocks, used & 255u, (used >> 8) & 255u) && box_holds(box_blocks, (used >> 16) & 255u, used >> 24));
+                const bool guess_ok = mrun <= rcap && mbucket <= bcap && mseg <= scap && in_box;
                 const uint32_t fl = (guess_ok ? 0u : 4u) | ((aborted && guess_ok) ? 2u : 0u);
                 total_host[0] = sum > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sum; total_host[2] = (uint32_t)sum; total_host[3] = (uint32_t)(sum >> 32); total_host[5] = mlist; total_host[1] = fl;
             } else { total_host[0] = total[0]; total_host[2] = total[2]; total_host[3] = total[3]; total_host[5] = total[4]; total_host[1] = total[1]; }
@@ -190,8 +193,8 @@ __global__ __launch_bounds__(64) void k_composite_v2(const float4* __restrict__ 
 
 template <bool PREMULT_C>
 static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int W, int H,
-                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs, const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t stage_seq, uint32_t rcap, uint32_t scap, uint32_t bcap, unsigned long long* stamps) {
-#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, stamps)
+                            uint32_t* tstate, uint32_t epoch, float4 c, float4* fb, int kp, int rp, uint32_t slabs, const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t stage_seq, uint32_t rcap, uint32_t scap, uint32_t bcap, TileBox box, uint32_t box_blocks, unsigned long long* stamps) {
+#define GS4D_V2(P) k_composite_v2<PREMULT_C, P><<<grid, dim3(64), 0, st>>>(proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, box, box_blocks, stamps)
     switch (per) {
     case 1: GS4D_V2(1); break;
     case 2: GS4D_V2(2); break;
@@ -208,11 +211,14 @@ static hipError_t launch_v2(hipStream_t st, int per, dim3 grid, const float4* pr
 
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs,
-                               const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t stage_seq, uint32_t rcap, uint32_t scap, uint32_t bcap) {
+                               const uint4* bstat, uint32_t nb, const uint32_t* sstat, uint32_t rows, uint32_t stage_seq, uint32_t rcap, uint32_t scap, uint32_t bcap, uint32_t box_blocks) {
     if (hint > V2_MAX_LIST) return hipErrorInvalidValue;
     const int per = (int)(v2_list_capacity(hint) / 64u);
     const float4 c = make_float4(clear[0], clear[1], clear[2], clear[3]);
-    const dim3 grid(composite_grid(tiles_x, tiles_y));
+    // staged draws: only the box of tiles the list kernel has checked every entry to lie in (TileLists::box); the first workgroup reports, so there is always one
+    TileBox box = tile_box(stage_seq ? box_blocks : BOX_NONE, tiles_x, tiles_y);
+    if (box.w == 0u || box.h == 0u) box = TileBox{ 0u, 0u, 1u, 1u };
+    const dim3 grid(composite_grid((int)box.w, (int)box.h));
     int kp = (keybits + WS_DIGIT_BITS - 1) / WS_DIGIT_BITS, rp = (recbits + WS_DIGIT_BITS - 1) / WS_DIGIT_BITS;
 #ifdef GS4D_TUNING
     { static const bool nosort = getenv("GS4D_V2_NOSORT") != nullptr; if (nosort) kp = rp = 0; }      // ablation: what the wave-local list sort costs the kernel (the image is then wrong)
@@ -226,8 +232,8 @@ hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* 
     const bool stamp_now = stampf && ++calls == stamp_call;
     if (stamp_now && (hipMalloc(&stamps, (size_t)grid.x * 48) != hipSuccess || hipMemsetAsync(stamps, 0, (size_t)grid.x * 48, st) != hipSuccess)) stamps = nullptr;
 #endif
-    const hipError_t le = premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, stamps)
-                                    : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, stamps);
+    const hipError_t le = premult_c ? launch_v2<true>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, box, box_blocks, stamps)
+                                    : launch_v2<false>(st, per, grid, proj, entries, tstart, tcnt, total, total_host, tiles_x, W, H, tstate, epoch, c, fb, kp, rp, slabs, bstat, nb, sstat, rows, stage_seq, rcap, scap, bcap, box, box_blocks, stamps);
 #ifdef GS4D_TUNING
     if (stamps) {
         (void)hipStreamSynchronize(st);

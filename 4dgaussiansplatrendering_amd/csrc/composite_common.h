@@ -35,6 +35,23 @@ __device__ __forceinline__ bool composite_tile(uint32_t wg, int tiles_x, int til
     tile = ty * (uint32_t)tiles_x + tx;
     return tx < (uint32_t)tiles_x && ty < (uint32_t)tiles_y;
 }
+// The same walk over a BOX of tiles (x0, y0, w, h — in tiles) of an image that is tiles_x tiles wide: the grid is composite_grid(w, h).
+struct TileBox { uint32_t x0, y0, w, h; };
+static_assert(TBLOCK == BOX_BLOCK, "a launch box is whole blocks of the compositor's walk");
+// box: TileLists::box (blocks, inclusive; BOX_NONE = everything), clipped to the image
+__host__ __device__ __forceinline__ TileBox tile_box(uint32_t box, int tiles_x, int tiles_y) {
+    if (box == BOX_NONE) return TileBox{ 0u, 0u, (uint32_t)tiles_x, (uint32_t)tiles_y };
+    const uint32_t x0 = (box & 255u) * BOX_BLOCK, y0 = ((box >> 8) & 255u) * BOX_BLOCK;
+    const uint32_t x1 = (((box >> 16) & 255u) + 1u) * BOX_BLOCK, y1 = ((box >> 24) + 1u) * BOX_BLOCK;
+    const uint32_t cx1 = x1 < (uint32_t)tiles_x ? x1 : (uint32_t)tiles_x, cy1 = y1 < (uint32_t)tiles_y ? y1 : (uint32_t)tiles_y;
+    return TileBox{ x0, y0, cx1 > x0 ? cx1 - x0 : 0u, cy1 > y0 ? cy1 - y0 : 0u };
+}
+__device__ __forceinline__ bool composite_tile(uint32_t wg, int tiles_x, TileBox box, uint32_t& tile) {
+    uint32_t t;
+    const bool real = composite_tile(wg, (int)box.w, (int)box.h, t);
+    tile = (box.y0 + t / box.w) * (uint32_t)tiles_x + box.x0 + t % box.w;
+    return real;
+}
 
 // glBlendFunc factors (GL enum values; the set the reference's menu offers, DebugMenus.h:41-59).  The reference never calls glBlendColor:
 // the blend colour stays (0, 0, 0, 0), so CONSTANT_* = 0 and ONE_MINUS_CONSTANT_* = 1.

@@ -161,6 +161,7 @@ struct gs4d_ctx {
              int key_mode = 0; uint32_t bias = 0, span = 0xFFFFFFFFu; float view[16] = { 0 }; } po;
     int blend_src = GS4D_SRC_ALPHA, blend_dst = GS4D_ONE_MINUS_SRC_ALPHA;     // glBlendFunc state (Application.cpp:137-138, 150)
     bool defer_order = true;           // GS4D_FUSE_KEYGEN=0 switches the deferral off (test hook)
+    uint64_t stat_composited_tiles = 0;      // tiles the compositing kernel of the last unordered draw was launched for (staged draws: the launch box)
     uint64_t stat_fused = 0, stat_renamed = 0, stat_shadow_bytes = 0, stat_streams_rejected = 0, stat_lanes_sharing = 0;      // lanes_sharing: lanes that had to take a stream which shares a hardware queue with another lane
     bool rename_storage = true;        // GS4D_RENAME=0 switches the storage exchange off (test hook)
     int shrink_votes = 0;
@@ -174,8 +175,10 @@ struct gs4d_ctx {
     // the draws that follow let the projection kernel write the list entries itself — one dense block per segment, sized by those statistics plus a
     // margin — no scan and no scatter kernel.  The device checks the guess; a draw that does not fit is re-run exactly.  GS4D_STAGED=0 switches it
     // off (test hook).
-    bool stage_enable = true, stage_known = false;
+    bool stage_enable = true, stage_known = false, stage_box_enable = true;
     uint32_t stage_max_run = 0, stage_max_bucket = 0, stage_max_seg = 0; uint64_t stage_geom = 0;
+    uint32_t stage_box_margin = 1;  // blocks added on every side of it; doubled (up to 16) whenever a draw had entries outside its box
+    uint32_t stage_box = BOX_NONE;  // blocks of tiles that held entries in the last staged draw of this geometry (TileLists::box); BOX_NONE: not known
     uint64_t stat_staged = 0, stat_staged_misses = 0;
     uint64_t stat_v2_draws = 0, stat_longest = 0;
     // profiling: a ring of per-frame event pairs; a frame ends with its draw
@@ -391,7 +394,7 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
         if (a.fuse) { Buffer* K = getbuf(c, a.fuse_keys); if (K) fused_keys = (const uint32_t*)K->d; }      // the projection wrote the keys there and nowhere else
         if (L.tl.staged) {
             // staged: the projection kernel wrote the segment blocks; one kernel turns them into tile lists and checks what the host guessed
-            HIPCHK(c, launch_bucket_tiles_staged(L.s, L.tl, ntiles, L.bin.total, entries, c->list_hint));
+            HIPCHK(c, launch_bucket_tiles_staged(L.s, L.tl, ntiles, c->tiles_x, L.bin.total, entries, c->list_hint));
             c->stat_staged++;
         } else {
             if (!skip_lists) {
@@ -408,8 +411,9 @@ int enqueue_raster_v2(gs4d_ctx* c, Lane& L, Framebuffer& F, const DrawArgs& a, s
     {
         StageTimer t(c, GS4D_T_COMPOSITE);
         HIPCHK(c, launch_composite_v2(L.s, L.proj, entries, L.tl.tstart, L.tl.tcnt, L.bin.total, L.host_total_dev, c->tiles_x, c->tiles_y, c->W, c->H, premult_c, F.tstate, F.epoch, a.clear, F.mem,
-                                      c->list_hint, a.keybits, recbits, L.tl.slabs, L.tl.bstat, L.tl.nb, L.tl.sstat, L.tl.rows, L.tl.staged ? L.tl.seq : 0u, 0xFFFFFFFFu, L.tl.scap, L.tl.bcap));
+                                      c->list_hint, a.keybits, recbits, L.tl.slabs, L.tl.bstat, L.tl.nb, L.tl.sstat, L.tl.rows, L.tl.staged ? L.tl.seq : 0u, 0xFFFFFFFFu, L.tl.scap, L.tl.bcap, L.tl.box));
     }
+    { const uint32_t b = L.tl.staged ? L.tl.box : BOX_NONE; c->stat_composited_tiles = b == BOX_NONE ? ntiles : (uint64_t)std::min<uint32_t>((((b >> 16) & 255u) - (b & 255u) + 1u) * BOX_BLOCK, (uint32_t)c->tiles_x) * std::min<uint32_t>(((b >> 24) - ((b >> 8) & 255u) + 1u) * BOX_BLOCK, (uint32_t)c->tiles_y); }
     HIPCHK(c, hipEventRecord(L.ev_emit, L.s));         // totals, flags and the longest list are in pinned host memory behind this event (the compositor's first workgroup wrote them)
     return GS4D_OK;
 }
@@ -446,7 +450,7 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
     HIPCHK(c, bin_scratch_reserve(L.s, L.bin, a.instances, (size_t)c->tiles_x * c->tiles_y));
     bool v2 = a.v2 && tile_lists_plan(L.tl, (size_t)c->tiles_x * c->tiles_y, npre, c->slabs, a.keybits, a.key_span);
     if (v2) { HIPCHK(c, tile_lists_reserve(L.s, L.tl, (size_t)c->tiles_x * c->tiles_y, npre)); preprocess = true; order = nullptr; }   // an unordered draw is always re-run from the projection
-    L.tl.staged = false; L.tl.scap = L.tl.bcap = 0;
+    L.tl.staged = false; L.tl.scap = L.tl.bcap = 0; L.tl.box = BOX_NONE;
     if (v2) {
         // the statistics of a draw belong to a list geometry (buckets, segments, tiles, records, shard, data buffer): another one starts from scratch
         uint64_t geom = 0xcbf29ce484222325ull;
@@ -461,6 +465,13 @@ int run_draw(gs4d_ctx* c, const DrawArgs& a, bool preprocess) {
                 HIPCHK(c, tile_lists_reserve_blocks(L.s, L.tl, (size_t)L.tl.rows * scap));
                 L.tl.staged = true; L.tl.scap = (uint32_t)scap; L.tl.bcap = (uint32_t)bcap;
                 if (++L.tl.seq == 0u) L.tl.seq = 1u;
+                // the compositor's launch box: where the last staged draw had entries, stage_box_margin blocks (of 4 x 4 tiles) wider on every side
+                const uint32_t nbx = (uint32_t)(c->tiles_x + BOX_BLOCK - 1) / BOX_BLOCK, nby = (uint32_t)(c->tiles_y + BOX_BLOCK - 1) / BOX_BLOCK;
+                if (c->stage_box_enable && c->stage_box != BOX_NONE && c->stage_box != BOX_EMPTY && nbx <= 256u && nby <= 256u) {
+                    const uint32_t b = c->stage_box, x0 = b & 255u, y0 = (b >> 8) & 255u, x1 = (b >> 16) & 255u, y1 = b >> 24;
+                    const uint32_t m = c->stage_box_margin;
+                    L.tl.box = box_pack(x0 > m ? x0 - m : 0u, y0 > m ? y0 - m : 0u, std::min(x1 + m, nbx - 1u), std::min(y1 + m, nby - 1u));
+                }
             }
         }
     }
@@ -584,6 +595,10 @@ int resolve_lane(gs4d_ctx* c, int li) {
         if (L.pending_args.v2 && !(flags & 1u)) {
             // longest (bucket, segment) run and fullest bucket of this draw: what sizes the staged blocks of the draws that follow
             c->stage_max_run = L.host_total[6]; c->stage_max_bucket = L.host_total[7]; c->stage_max_seg = L.host_total[8]; c->stage_geom = L.pending_args.stage_geom; c->stage_known = true;
+            c->stage_box = L.host_total[9];
+            const uint32_t u = L.host_total[9];
+            if ((flags & 4u) && L.tl.box != BOX_NONE && u != BOX_NONE && u != BOX_EMPTY && !(box_holds(L.tl.box, u & 255u, (u >> 8) & 255u) && box_holds(L.tl.box, (u >> 16) & 255u, u >> 24)))
+                c->stage_box_margin = std::min(16u, c->stage_box_margin * 2u);      // the picture moves faster than the margin allowed
         }
         if (L.pending_args.v2) {
             c->stat_longest = L.host_total[5];
@@ -772,6 +787,7 @@ int gs4d_create(int device, int width, int height, gs4d_ctx** out) {
     if (const char* ev = getenv("GS4D_FUSE_KEYGEN")) c->defer_order = atoi(ev) != 0;                                       // test hook: 0 = launch key generation and sort at once
     if (const char* ev = getenv("GS4D_DRAW_PATH")) { if (!strcmp(ev, "ordered")) c->path_pref = 1; }
     if (const char* ev = getenv("GS4D_RENAME")) c->rename_storage = atoi(ev) != 0;
+    if (const char* ev = getenv("GS4D_STAGED_BOX")) c->stage_box_enable = atoi(ev) != 0;                                   // test hook: 0 = the compositor of a staged draw is launched for every tile
     if (const char* ev = getenv("GS4D_STAGED")) c->stage_enable = atoi(ev) != 0;                                          // test hook: 0 = every unordered draw builds its lists exactly (scan + scatter)
     if (const char* ev = getenv("GS4D_SLABS")) { const int v = atoi(ev); if (v >= 1 && v <= (int)V2_MAX_SLABS) { c->slabs = 1; while ((int)c->slabs < v) c->slabs *= 2u; } }      // test hook: depth slabs (a power of two)                         // test hook: instance-ordered tile lists for every draw
     auto bail = [&](int rc) { g_create_error = c->err; gs4d_destroy(c); return rc; };
@@ -1475,7 +1491,7 @@ int gs4d_get_stats(gs4d_ctx* c, uint64_t stats[8]) {
     if (!c || !stats) return GS4D_E_INVALID;
     (void)hipSetDevice(c->device);
     int rc = resolve_pending(c); if (rc) return rc;
-    stats[0] = (c->stat_entries & 0xFFFFFFFFull) | (c->stat_staged << 32); stats[1] = ((uint64_t)lane(c).pair_cap & 0xFFFFFFFFFFull) | (c->stat_staged_misses << 40); stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y | (c->stat_shadow_bytes << 32);
+    stats[0] = (c->stat_entries & 0xFFFFFFFFull) | (c->stat_staged << 32); stats[1] = ((uint64_t)lane(c).pair_cap & 0xFFFFFFFFFFull) | (c->stat_staged_misses << 40); stats[2] = (c->stat_reruns & 0xFFFFFFFFull) | (c->stat_aborted_discarded << 32); stats[3] = (uint64_t)c->tiles_x * c->tiles_y | ((c->stat_shadow_bytes & 0xFFull) << 32) | ((c->stat_composited_tiles & 0xFFFFFFull) << 40);
     stats[4] = (c->stat_depth_passes & 0xFFFFFFFFull) | (c->stat_streams_rejected << 32); stats[5] = (c->stat_tile_passes & 0xFFFFFFFFull) | (c->stat_renamed << 32); stats[6] = (uint64_t)(c->nlanes & 0xFFFF) | (c->stat_lanes_sharing << 16) | (c->stat_fused << 32); stats[7] = c->stat_v2_draws | (c->stat_longest << 32);
     return GS4D_OK;
 }

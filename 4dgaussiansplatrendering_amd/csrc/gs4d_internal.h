@@ -170,7 +170,21 @@ struct TileLists {
     uint32_t* sstat = nullptr;                                 // [1024]
     bool staged = false; uint32_t scap = 0, bcap = 0;         // the current draw is staged; entries a segment block holds, bucket capacity in the tile-ordered entry array
     uint32_t seq = 0;                                          // sequence number of the lane's staged draws: total[TL_ABORT_WORD] == seq <=> this draw was aborted
+    // staged draws: the BOX of tiles (in blocks of BOX_BLOCK x BOX_BLOCK tiles, both ends inclusive, box_pack) outside which the host expects no entry — a third guess
+    // from the previous frames' statistics (bstat[b].w: the box of bucket b's non-empty tiles), checked by k_bucket_tiles_staged like the two capacities;
+    // the compositor is launched for these tiles only.  BOX_NONE: the whole image.
+    uint32_t box = 0xFFFFFFFFu;
 };
+constexpr uint32_t BOX_BLOCK = 4u, BOX_NONE = 0xFFFFFFFFu, BOX_EMPTY = 0x0000FFFFu;      // BOX_EMPTY: min 255, max 0 in both directions — the neutral element of box_join
+__host__ __device__ __forceinline__ uint32_t box_pack(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) { return x0 | (y0 << 8) | (x1 << 16) | (y1 << 24); }
+__host__ __device__ __forceinline__ uint32_t box_join(uint32_t a, uint32_t b) {
+    const uint32_t x0 = (a & 255u) < (b & 255u) ? (a & 255u) : (b & 255u), y0 = ((a >> 8) & 255u) < ((b >> 8) & 255u) ? ((a >> 8) & 255u) : ((b >> 8) & 255u);
+    const uint32_t x1 = ((a >> 16) & 255u) > ((b >> 16) & 255u) ? ((a >> 16) & 255u) : ((b >> 16) & 255u), y1 = (a >> 24) > (b >> 24) ? (a >> 24) : (b >> 24);
+    return box_pack(x0, y0, x1, y1);
+}
+__host__ __device__ __forceinline__ bool box_holds(uint32_t box, uint32_t bx, uint32_t by) {      // block (bx, by) inside the box
+    return box == BOX_NONE || (bx >= (box & 255u) && bx <= ((box >> 16) & 255u) && by >= ((box >> 8) & 255u) && by <= (box >> 24));
+}
 constexpr int TL_ABORT_WORD = 9;                              // index into BinScratch::total
 // false: this frame / record count cannot use the unordered path (more than 256 * 1024 tiles, or 2^24 records)
 // key_span: host-proven largest blend key (the slabs divide [0, key_span] evenly)
@@ -185,13 +199,13 @@ hipError_t launch_bucket_scatter(hipStream_t st, TileLists& t, const uint32_t* t
 hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, const uint2* tmp, uint2* entries, uint32_t hint);
 // staged draws: the segment blocks the projection kernel wrote (t.blocks, t.scap) -> tile lists at entries[b * t.bcap ...]; per-bucket statistics into t.bstat;
 // total[TL_ABORT_WORD] = t.seq when a run, a bucket or a list does not fit
-hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint2* entries, uint32_t hint);
+hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, int tiles_x, uint32_t* total, uint2* entries, uint32_t hint);
 hipError_t tile_lists_reserve_blocks(hipStream_t st, TileLists& t, size_t entries);
 // bstat / nb, sstat / rows: per-bucket and per-segment statistics for the host report; stage_seq != 0: a staged draw (aborted <=> total[TL_ABORT_WORD] == stage_seq,
 // the entry total is the sum of the statistics); rcap / scap / bcap: what the host guessed for it (longest run: no limit any more, 0xFFFFFFFF; fullest segment; fullest bucket)
 hipError_t launch_composite_v2(hipStream_t st, const float4* proj, const uint2* entries, const uint32_t* tstart, const uint32_t* tcnt, const uint32_t* total, uint32_t* total_host, int tiles_x, int tiles_y, int W, int H,
                                int premult_c, uint32_t* tstate, uint32_t epoch, const float clear[4], float4* fb, uint32_t hint, int keybits, int recbits, uint32_t slabs,
-                               const uint4* bstat = nullptr, uint32_t nb = 0, const uint32_t* sstat = nullptr, uint32_t rows = 0, uint32_t stage_seq = 0, uint32_t rcap = 0, uint32_t scap = 0, uint32_t bcap = 0);
+                               const uint4* bstat = nullptr, uint32_t nb = 0, const uint32_t* sstat = nullptr, uint32_t rows = 0, uint32_t stage_seq = 0, uint32_t rcap = 0, uint32_t scap = 0, uint32_t bcap = 0, uint32_t box_blocks = 0xFFFFFFFFu);
 
 #ifdef __HIPCC__
 // tiles touched by a pixel rectangle (x0|y0<<16, x1|y1<<16; x0 > x1: none), restricted to the tile rows ty % world == rank

@@ -247,9 +247,10 @@ __global__ __launch_bounds__(BT_THREADS) void k_bucket_tiles(const uint2* __rest
 template <int KMAX, int THREADS>
 __global__ __launch_bounds__(THREADS) void k_bucket_tiles_staged(const uint2* __restrict__ blocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t rows, uint32_t scap,
                                                                     uint32_t bcap, uint32_t nb, uint32_t ntiles, uint32_t slabs, uint32_t slab_shift, uint32_t nc, uint32_t* __restrict__ tstart,
-                                                                    uint32_t* __restrict__ tcnt, uint2* __restrict__ entries, uint4* __restrict__ bstat, uint32_t* __restrict__ abort_word, uint32_t seq, uint32_t hint) {
+                                                                    uint32_t* __restrict__ tcnt, uint2* __restrict__ entries, uint4* __restrict__ bstat, uint32_t* __restrict__ abort_word, uint32_t seq, uint32_t hint,
+                                                                    uint32_t tiles_x, uint32_t box) {
     extern __shared__ uint32_t cnt[];                      // [nc]
-    __shared__ uint32_t ws[THREADS / 64], wm[THREADS / 64];
+    __shared__ uint32_t ws[THREADS / 64], wm[THREADS / 64], wb[THREADS / 64];
     __shared__ uint32_t rp[1025], ro[1024];                // rp[w]: entries of the bucket before run w (rp[rows] = all of them); ro[w]: where run w starts in `blocks` (rows <= 1024: tile_lists_plan)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6, b = blockIdx.x;
     const uint32_t sl = (uint32_t)__ffs((int)slabs) - 1u;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_tiles_staged(const uint2* __
     const uint32_t per = (T + THREADS - 1u) / THREADS;     // entries per thread
     const bool fits = T <= bcap && per <= (uint32_t)KMAX;   // uniform
     if (!fits) {
-        if (tid == 0u) { bstat[b] = make_uint4(T, maxrun, 0u, 0u); *abort_word = seq; }
+        if (tid == 0u) { bstat[b] = make_uint4(T, maxrun, 0u, BOX_EMPTY); *abort_word = seq; }
         return;
     }
     __syncthreads();                                        // rp / ro complete; ws / wm are reused below
@@ -327,6 +328,7 @@ __global__ __launch_bounds__(THREADS) void k_bucket_tiles_staged(const uint2* __
     for (int k = 0; k < THREADS / 64; ++k) { if ((unsigned)k < w) wbase += ws[k]; longest = max(longest, wm[k]); }
     const uint32_t lo_e = b * bcap;
     uint32_t runpos = lo_e + wbase + inc - sum;
+    uint32_t mybox = BOX_EMPTY;                             // the blocks of this thread's tiles that hold entries
     for (uint32_t k = 0; k < cpt; ++k) {
         const uint32_t q = q0c + k;
         if (q < nc) {
@@ -334,10 +336,23 @@ __global__ __launch_bounds__(THREADS) void k_bucket_tiles_staged(const uint2* __
             cnt[q] = runpos;
             const uint32_t tile = (q >> sl) * nb + b;
             if (tile < ntiles) { tstart[(size_t)tile * slabs + (q & (slabs - 1u))] = runpos; tcnt[(size_t)tile * slabs + (q & (slabs - 1u))] = cq; }
+            if (cq) { const uint32_t bx = min(255u, (tile % tiles_x) / BOX_BLOCK), by = min(255u, (tile / tiles_x) / BOX_BLOCK); mybox = box_join(mybox, box_pack(bx, by, bx, by)); }
             runpos += cq;
         }
     }
-    if (tid == 0u) { bstat[b] = make_uint4(T, maxrun, longest, 0u); if (longest > hint) *abort_word = seq; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mybox = box_join(mybox, (uint32_t)__shfl_xor((int)mybox, off, 64));
+    if (lane == 0u) wb[w] = mybox;
+    __syncthreads();
+    if (tid == 0u) {
+        uint32_t bb = BOX_EMPTY;
+#pragma unroll
+        for (int k = 0; k < THREADS / 64; ++k) bb = box_join(bb, wb[k]);
+        bstat[b] = make_uint4(T, maxrun, longest, bb);
+        // an entry outside the box the compositor is launched for (a guess, like the capacities): the draw is re-run exactly, over the whole image
+        const bool outside = bb != BOX_EMPTY && !(box_holds(box, bb & 255u, (bb >> 8) & 255u) && box_holds(box, (bb >> 16) & 255u, bb >> 24));
+        if (longest > hint || outside) *abort_word = seq;
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) if (s0 + (uint32_t)k < s1) {
@@ -441,12 +456,12 @@ hipError_t launch_bucket_tiles(hipStream_t st, TileLists& t, size_t ntiles, uint
     return hipGetLastError();
 }
 
-hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, uint32_t* total, uint2* entries, uint32_t hint) {
+hipError_t launch_bucket_tiles_staged(hipStream_t st, TileLists& t, size_t ntiles, int tiles_x, uint32_t* total, uint2* entries, uint32_t hint) {
     // 512 threads: the same time alone as with 1024, 4 % more frames per second with the frame lanes overlapping (0.0955-0.0961 against 0.0992-0.1018 ms per
     // frame at C2, alternating runs) — an 8-wave workgroup finds room on a busy CU sooner than a 16-wave one.  A thread holds up to 16 (buckets of <= 8192
     // entries: what tile_lists_plan aims at) or 32 entries.
 #define GS4D_BTS(K) k_bucket_tiles_staged<K, 512><<<dim3(t.nb), dim3(512), t.counters * 4u, st>>>(t.blocks, t.hist, t.hist + t.hist_cap, t.rows, t.scap, t.bcap, t.nb, (uint32_t)ntiles, t.slabs, t.slab_shift, \
-                                                                                                 t.counters, t.tstart, t.tcnt, entries, t.bstat, total + TL_ABORT_WORD, t.seq, hint)
+                                                                                                 t.counters, t.tstart, t.tcnt, entries, t.bstat, total + TL_ABORT_WORD, t.seq, hint, (uint32_t)tiles_x, t.box)
     if (t.bcap <= 16u * 512u) GS4D_BTS(16);
     else if (t.bcap <= 32u * 512u) GS4D_BTS(32);
     else return hipErrorInvalidValue;                      // run_draw does not stage such a draw

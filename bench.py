@@ -180,7 +180,22 @@ def roofline_block(gs4d_stats, stage_ms, warm_ms, n, ms_per_step, traffic_file, 
     return out
 
 
-def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None, keybufs=4, steady_stages=0, four_d=False, t=0.0, settle_window=False):
+def morton_order(pos):
+    """--spatial-order (an experiment, never the headline): the permutation that puts splats which are neighbours in space next to each other in
+    the record buffer (30-bit Morton code of the position).  BASELINE.json's splats are in random order; what the order of the records is worth
+    says where the gathers of the compositing kernels spend their time (profiles/r04_experiments.txt, item 13)."""
+    g = np.clip((pos - pos.min(0)) / (pos.max(0) - pos.min(0)) * 1023.0, 0, 1023).astype(np.uint64)
+
+    def spread(v):
+        v = (v | (v << 16)) & np.uint64(0x030000FF)
+        v = (v | (v << 8)) & np.uint64(0x0300F00F)
+        v = (v | (v << 4)) & np.uint64(0x030C30C3)
+        v = (v | (v << 2)) & np.uint64(0x09249249)
+        return v
+    return np.argsort(spread(g[:, 0]) | (spread(g[:, 1]) << np.uint64(1)) | (spread(g[:, 2]) << np.uint64(2)), kind="stable")
+
+
+def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events=True, lanes=None, keybufs=4, steady_stages=0, four_d=False, t=0.0, settle_window=False, spatial_order=False):
     """One GPU: static 3D splats in the cube (configs[1] / configs[2]) or, four_d, the true 4D splats of configs[3] at time t.
     Returns (result dict, records, camera)."""
     cam = scenes.CAM_CUBE
@@ -192,6 +207,9 @@ def measure_single(gs4d, scenes, n, steps, warmup, windows, device, stage_events
         del pos4, q, scale, life, fade, vel, rgba
     else:
         pos, q, scale, rgba = scenes.cube_params(n)
+        if spatial_order:
+            o = morton_order(pos)
+            pos, q, scale, rgba = pos[o], q[o], scale[o], rgba[o]
         rec = gs4d.build_records_3d(pos, q, scale, rgba)
         del pos, q, scale, rgba
     sc = Scene(gs4d, rec, cam, view, proj, device, lanes=lanes, keybufs=keybufs)
@@ -268,6 +286,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=None, help="frame lanes of the context (default: the library's, 4); experiments")
     ap.add_argument("--keybufs", type=int, default=None, help="key / sort-index buffer pairs the application cycles through (default: one per lane)")
     ap.add_argument("--four-d", action="store_true", help="N=1: the main workload is configs[3]'s set of true 4D splats at t = 25 instead of the static cube (profiling the c4_n1 block's kernels: tools/profile_round.sh)")
+    ap.add_argument("--spatial-order", action="store_true", help="N=1, an experiment: the static splats are uploaded in Morton order of their positions instead of BASELINE.json's random order (the line says so in config.workload)")
     ap.add_argument("--no-c3", action="store_true", help="N=1: skip the configs[2] and c4_n1 blocks (10^7 splats; 10^6 4D splats)")
     ap.add_argument("--no-latency", action="store_true", help="N=1: skip the one-lane frame time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -306,7 +325,7 @@ def main():
 def single_gpu(args, gs4d, scenes, device):
     n = args.splats
     kb = args.keybufs or args.lanes or 4          # one pair per frame lane (the library default is 4 lanes)
-    fd = dict(four_d=True, t=25.0) if args.four_d else {}
+    fd = dict(four_d=True, t=25.0) if args.four_d else dict(spatial_order=True) if args.spatial_order else {}
     res, rec, (cam, view, proj) = measure_single(gs4d, scenes, n, args.steps, args.warmup, args.windows, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb, **fd)
     tag = "c4" if args.four_d else "c2" if n == 1_000_000 else "c3" if n == 10_000_000 else "x"
     tfile = lambda t: os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_{t}.json")
@@ -317,7 +336,7 @@ def single_gpu(args, gs4d, scenes, device):
     side = not args.no_c3 and n == 1_000_000 and not args.four_d
     r3 = r4 = None
     if side:
-        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 8, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb)
+        r3, _, _ = measure_single(gs4d, scenes, n3, max(10, min(args.steps, 100) // 2), 8, 3, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb, spatial_order=args.spatial_order)
         # configs[3]'s workload on ONE GPU: 10^6 true 4D splats (96-byte records: nothing of sig is constant or symmetric-by-construction here), t mid-sweep
         r4, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 100), 24, 5, device, stage_events=not args.no_stage_events, lanes=args.lanes, keybufs=kb, four_d=True, t=25.0, settle_window=True)
     one_pair = None
@@ -331,7 +350,7 @@ def single_gpu(args, gs4d, scenes, device):
     if not args.no_latency:
         one, _, _ = measure_single(gs4d, scenes, n, min(args.steps, 50), min(args.warmup, 10), 3, device, stage_events=False, lanes=1, steady_stages=16, **fd)
         if side:
-            one3, _, _ = measure_single(gs4d, scenes, n3, 10, 5, 3, device, stage_events=False, lanes=1, steady_stages=8)
+            one3, _, _ = measure_single(gs4d, scenes, n3, 10, 5, 3, device, stage_events=False, lanes=1, steady_stages=8, spatial_order=args.spatial_order)
             one4, _, _ = measure_single(gs4d, scenes, n, 30, 10, 3, device, stage_events=False, lanes=1, steady_stages=16, four_d=True, t=25.0)
     roofline = roofline_block(res["stats"], res["stage_ms"], res["warm_ms"], n, res["ms_per_step"], tfile(tag), one)
 
@@ -357,10 +376,11 @@ def single_gpu(args, gs4d, scenes, device):
         "timed_window_attempts": res["timed_window_attempts"],
         "latency_ms_one_lane": round(one["ms_per_step"], 5) if one else None,
         "config": {"workload": (f"{n:,} 4D splats of BASELINE.json configs[3]'s set at t = 25, single 1080p frame, one GPU" if args.four_d else
-                                f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else "")),
+                                f"{n:,} random 3D splats in a 400^3 cube, single 1080p frame" + (" (BASELINE.json configs[1])" if n == 1_000_000 else " (BASELINE.json configs[2])" if n == 10_000_000 else "") +
+                                (" — EXPERIMENT --spatial-order: records uploaded in Morton order of their positions, not the configuration's random order" if args.spatial_order else "")),
                    "splats": n, "width": W, "height": H, "sort": "on", "frames_per_step": 1, "frame_lanes": st["lanes"],
                    "tile_list_entries": st["entries"], "longest_tile_list": st["longest_list"], "unordered_draws": st["unordered_draws"], "staged_list_draws": st["staged_draws"], "overflow_reruns": st["reruns"],
-                   "depth_sort_passes": st["depth_sort_passes"], "record_bytes_read_by_projection": st["record_read_bytes"],
+                   "depth_sort_passes": st["depth_sort_passes"], "record_bytes_read_by_projection": st["record_read_bytes"], "tiles_composited": st["composited_tiles"], "tiles": st["tiles"],
                    "aborted_frames_in_timed_windows": res["aborted_in_timed_windows"], "key_index_buffer_pairs": kb, "lane_streams_rejected_at_create": st["lane_streams_rejected"], "lanes_sharing_a_hardware_queue": st["lanes_sharing_a_queue"]},
         "one_key_index_pair": one_pair,
         "roofline": roofline,

@@ -168,7 +168,7 @@ GS4D_API int gs4d_get_timings(gs4d_ctx* ctx, float ms[GS4D_T_COUNT]);           
 /* Start and end of every timed stage of the frames recorded so far (at most 128), in ms since the first timed stage of frame 0:
  * ms[frame][stage][2].  Shows how consecutive frames overlap.  Blocking; does not restart the ring (gs4d_get_timings does). */
 GS4D_API int gs4d_get_timeline(gs4d_ctx* ctx, float* ms, int max_frames, int* frames);
-GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[8]);                    /* [0] low 32 bits: tile-list entries of the last draw, high 32 bits: draws so far whose projection kernel wrote the list entries itself (staged lists: DESIGN.md 3c), [1] low 40 bits: capacity, high 24 bits: staged draws whose guess did not fit and that were re-run exactly, [2] low 32 bits: re-runs after overflow, high 32 bits: draws that aborted on the device and were cleared away unobserved (never re-run; a frame loop without read-backs checks this stays 0), [3] low 32 bits: tiles, high 32 bits: bytes per record the last 4D draw's projection read (64: static 3D splats, 72: symmetric sig, 96: anything),
+GS4D_API int gs4d_get_stats(gs4d_ctx* ctx, uint64_t stats[8]);                    /* [0] low 32 bits: tile-list entries of the last draw, high 32 bits: draws so far whose projection kernel wrote the list entries itself (staged lists: DESIGN.md 3c), [1] low 40 bits: capacity, high 24 bits: staged draws whose guess did not fit and that were re-run exactly, [2] low 32 bits: re-runs after overflow, high 32 bits: draws that aborted on the device and were cleared away unobserved (never re-run; a frame loop without read-backs checks this stays 0), [3] low 32 bits: tiles, bits 32-39: bytes per record the last 4D draw's projection read (64: static 3D splats, 72: symmetric sig, 96: anything), bits 40-63: tiles the compositing kernel of the last unordered draw was launched for (a staged draw: the box of tiles that held entries in the frames before, a few tiles wider — an entry outside it is found on the device and the draw re-run exactly, counted with the staged misses),
                                                                                       [4] low 32 bits: radix passes launched by the last gs4d_sort_pairs, high 32 bits: candidate streams gs4d_create discarded because they shared a hardware queue with a frame lane chosen before them (0 in a process without other streams), [5] low 32 bits: by the last draw's tile sort (0: the draw built unordered tile lists), high 32 bits: gs4d_keygen calls that gave their output buffers fresh storage instead of waiting for another frame lane (one key / index pair shared by all frames),
                                                                                       [6] bits 0..15: frame lanes, bits 16..31: lanes whose stream shares a hardware queue with another lane's (0 unless the process has fewer free queues than lanes: such a context runs ~10 % slower), high 32 bits: draws that generated the depth keys of the preceding gs4d_keygen themselves (see gs4d_keygen), [7] low 32 bits: draws so far on the unordered tile-list path, high 32 bits: longest tile list of the last such draw */
 /* Projected records of the last draw, 16 floats per record in record order:

@@ -195,3 +195,85 @@ def test_large_footprints_and_tiny_sets_are_staged_too(gs4d, oracle, monkeypatch
     assert np.array_equal(perm, eperm)
     assert np.abs(imgs[1].astype(np.float64) - eimg).max() <= TOL
     assert np.abs(eimg - oracle.CLEAR).max() > 0.05
+
+
+def test_the_compositor_is_launched_for_the_box_of_tiles_that_hold_entries(gs4d, oracle, monkeypatch):
+    """A far camera: the cube covers the middle of the image.  Once a staged draw has reported which blocks of tiles held entries, the compositing
+    kernel of the following staged draws is launched for that box (one block wider) only; the list kernel checks every non-empty tile against it.
+    Same picture, bit for bit, as with GS4D_STAGED_BOX=0 (every tile launched) and as the exact lists give."""
+    n, W, H = 150_000, 1280, 720
+    pos, q, scale, rgba = scenes.cube_params(n, seed=11)
+    rec = gs4d.build_records_3d(pos, q, scale * 2.0, rgba)
+    far = ((1400.0, 900.0, -500.0), scenes.CAM_CUBE[1])
+    imgs = {}
+    for box in ("1", "0"):
+        monkeypatch.setenv("GS4D_STAGED_BOX", box)
+        ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, staged=True)
+        for _ in range(12):
+            frame(ctx, gs4d, bufs, n, far, W, H)
+        imgs[box] = ctx.read_pixels()
+        st = ctx.stats()
+        ctx.close()
+        assert st["staged_draws"] >= 6 and st["staged_misses"] == 0 and st["reruns"] == 0, st
+        if box == "1":
+            assert 0 < st["composited_tiles"] < st["tiles"] // 2, st
+        else:
+            assert st["composited_tiles"] == st["tiles"], st
+    monkeypatch.delenv("GS4D_STAGED_BOX")
+    assert np.array_equal(imgs["1"].view(np.uint32), imgs["0"].view(np.uint32))
+    view, proj = mats(gs4d, far, W, H)
+    eimg, _, _ = oracle.render_4d(rec, True, 0.0, 0.0, far[0], view, proj, W, H)
+    assert np.abs(imgs["1"].astype(np.float64) - eimg).max() <= TOL
+    assert np.abs(eimg - oracle.CLEAR).max() > 0.05
+
+
+def test_entries_outside_the_launch_box_abort_the_draw_and_it_is_rerun(gs4d, oracle, monkeypatch):
+    """The camera turns between two frames so that the cube lands in another part of the image: the staged draw's list kernel finds entries outside
+    the box the compositor would be launched for, the draw aborts before a pixel is touched and is re-run exactly over the whole image; the next frames
+    learn the new box.  A slow pan stays inside the margin and never misses."""
+    n, W, H = 100_000, 1280, 720
+    pos, q, scale, rgba = scenes.cube_params(n, seed=12)
+    rec = gs4d.build_records_3d(pos, q, scale * 2.0, rgba)
+    eye = (1400.0, 900.0, -500.0)
+    d0 = np.array(scenes.CAM_CUBE[1], np.float64)
+
+    def turned(deg):
+        a = np.radians(deg)
+        d = np.array([d0[0] * np.cos(a) - d0[2] * np.sin(a), d0[1], d0[0] * np.sin(a) + d0[2] * np.cos(a)])
+        return (eye, tuple(float(x) for x in d))
+
+    ctx, bufs = make_ctx(gs4d, W, H, rec, monkeypatch, staged=True)
+    for _ in range(10):
+        frame(ctx, gs4d, bufs, n, turned(0.0), W, H)
+    ctx.finish()
+    s0 = ctx.stats()
+    assert s0["staged_misses"] == 0 and 0 < s0["composited_tiles"] < s0["tiles"], s0
+    # a slow pan: 0.05 degrees a frame (about a pixel and a half)
+    for k in range(1, 13):
+        frame(ctx, gs4d, bufs, n, turned(0.05 * k), W, H)
+    img = ctx.read_pixels()
+    s1 = ctx.stats()
+    assert s1["staged_misses"] == 0 and s1["reruns"] == 0, s1
+    cam = turned(0.6)
+    view, proj = mats(gs4d, cam, W, H)
+    eimg, _, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    assert np.abs(img.astype(np.float64) - eimg).max() <= TOL
+    # a jump of 12 degrees: the cube moves by a quarter of the image
+    cam = turned(12.0)
+    frame(ctx, gs4d, bufs, n, cam, W, H)
+    img = ctx.read_pixels()
+    s2 = ctx.stats()
+    assert s2["staged_misses"] >= 1 and s2["reruns"] >= 1, s2
+    view, proj = mats(gs4d, cam, W, H)
+    eimg, eperm, _ = oracle.render_4d(rec, True, 0.0, 0.0, cam[0], view, proj, W, H)
+    assert np.array_equal(ctx.read(bufs[2], np.uint32, n), eperm)
+    assert np.abs(img.astype(np.float64) - eimg).max() <= TOL
+    assert np.abs(eimg - oracle.CLEAR).max() > 0.05
+    for _ in range(10):
+        frame(ctx, gs4d, bufs, n, cam, W, H)
+    img2 = ctx.read_pixels()
+    s3 = ctx.stats()
+    ctx.close()
+    assert s3["staged_draws"] > s2["staged_draws"] and 0 < s3["composited_tiles"] < s3["tiles"], (s2, s3)
+    assert s3["staged_misses"] <= s2["staged_misses"] + 3
+    assert np.array_equal(img2.view(np.uint32), img.view(np.uint32))
