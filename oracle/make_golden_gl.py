@@ -101,7 +101,7 @@ def vs_fixture(name, kind, rec, t, min_opacity, view, proj, W, H, embed_records,
     c = corners_of(tf)
     arrays = {"uniforms": uni, "size": np.array([W, H], np.int32),
               "pos": c[:, :, 0:4], "sig": c[:, 0, 4:8], "color": c[:, 0, 8:12], "fragpos": c[:, :, 12:14]}
-    if kind == "4d":
+    if kind in ("4d", "4dmod"):
         arrays["faulty"] = (c[:, 0, 16] > 0).astype(np.uint8)
         arrays["topac"] = c[:, 0, 17]
     elif kind == "3d":
@@ -138,6 +138,7 @@ def img_fixture(name, kind, rec, t, min_opacity, cam_pos, view, proj, W, H, embe
         arrays["order"] = order
     elif kind == "4d":
         order = np.arange(len(rec), dtype=np.uint32)
+    # (kind "4dmod": Splat4DVertexShaderMod.GLSL has no sort index — instance k draws record k)
     want = [("img16" if unorm16 else "img")] + (["img8"] if want8 else [])
     res = gl_draw(kind, W, H, rec, order, uni, want, blend)
     if unorm16:
@@ -223,6 +224,8 @@ def main():
     for k, t in enumerate((0.0, 12.5, 49.0)):                                 # the times of linear_keys_t*
         vs_fixture(f"gl_vs_linear_first1000_t{k}", "4d", lin, t, 0.0, v, p, 1920, 1080, False, "linear_first1000")
     vs_fixture("gl_vs_linear_first1000_minop", "4d", lin, 3.0, 0.3, v, p, 1920, 1080, False, "linear_first1000")
+    # Splat4DVertexShaderMod.GLSL (Scenes.h:1765: the records at binding 1, no sort index) on the same records
+    vs_fixture("gl_vs_mod_linear_first1000_t1", "4dmod", lin, 12.5, 0.0, v, p, 1920, 1080, False, "linear_first1000")
     for blk, fixture in sd.BLOCKS:
         rec = ol.golden(fixture)
         for c, cam in enumerate(sd.cameras(ol)):
@@ -268,6 +271,7 @@ def main():
     v, p = VP(cam_n, 640, 360)
     img_fixture("gl_img_nonlinear_b45_640", "4d", nl, tm, 0.0, cam_n[0], v, p, 640, 360, False, "nonlinear_block45_first200")
     img_fixture("gl_img_nonlinear_b45_640_minop", "4d", nl, tm + 0.8, 0.25, cam_n[0], v, p, 640, 360, False, "nonlinear_block45_first200, uMinOpacity 0.25")
+    img_fixture("gl_img_mod_nonlinear_b45_640", "4dmod", nl, tm, 0.0, cam_n[0], v, p, 640, 360, False, "nonlinear_block45_first200, Splat4DVertexShaderMod.GLSL: record order", sorted_draw=False)
     for s, d, tag in ((1, 0x0303, "one_oneminus"), (0x0302, 1, "srcalpha_one")):      # two more pairs of DebugMenus.h:41-59's menu
         img_fixture(f"gl_img_nonlinear_b45_640_{tag}", "4d", nl, tm, 0.0, cam_n[0], v, p, 640, 360, False, "nonlinear_block45_first200", blend=(s, d), unorm16=True)
     for fixture, cam, where in OTHER:

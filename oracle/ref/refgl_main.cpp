@@ -4,7 +4,7 @@
 // fixtures it writes (tests/golden/gl_*) travel.  The product (libgs4d.so) never links, loads or calls it.
 //
 // What runs: the reference's shader TEXT, read unmodified at run time from $GS4D_REF (default /root/reference):
-//     Shader/Splats4D/Splat4DVertexShaderInstanced.GLSL + Splat4DFragShader.GLSL
+//     Shader/Splats4D/Splat4DVertexShaderInstanced.GLSL + Splat4DFragShader.GLSL   (and Splat4DVertexShaderMod.GLSL: kind 4dmod)
 //     Shader/Splats3D/Splat3DVertexShaderFull.GLSL      + Splat3DFragShaderFull.GLSL
 //     Shader/Splats2D/Splat2DVSI.GLSL                   + Splat2DFragShader.GLSL
 //     Shader/Lines/LineVert.GLSL                        + LineFrag.GLSL  (overlay lines)
@@ -206,12 +206,14 @@ static int cmd_draw(int argc, char** argv) {
     }
     if (ub.size() != 34 * 4) die("uniforms: expected 34 floats");
     const float* u = (const float*)ub.data();
+    const bool mod = kind == "4dmod";      // Splat4DVertexShaderMod.GLSL: the records at binding 1, no sort index (Scenes.h:1765, 1800-1808)
+    if (mod) kind = "4d";
     const size_t recsz = kind == "4d" ? 96 : kind == "3d" ? 4 * 72 : kind == "2d" ? 48 : 0;
-    if (!recsz) die("draw: kind must be 4d, 3d or 2d");
+    if (!recsz) die("draw: kind must be 4d, 4dmod, 3d or 2d");
     if (rec.size() != recsz * (size_t)n) die("records: %zu bytes for %ld records of %zu", rec.size(), n, recsz);
 
     const char *vs, *fs; std::vector<const char*> tfv;
-    if (kind == "4d")      { vs = "Shader/Splats4D/Splat4DVertexShaderInstanced.GLSL"; fs = "Shader/Splats4D/Splat4DFragShader.GLSL";
+    if (kind == "4d")      { vs = mod ? "Shader/Splats4D/Splat4DVertexShaderMod.GLSL" : "Shader/Splats4D/Splat4DVertexShaderInstanced.GLSL"; fs = "Shader/Splats4D/Splat4DFragShader.GLSL";
                              tfv = { "gl_Position", "oSig", "oColor", "oFragPos", "oFaulty", "oTimeOpacity" }; }          // 18 floats
     else if (kind == "3d") { vs = "Shader/Splats3D/Splat3DVertexShaderFull.GLSL"; fs = "Shader/Splats3D/Splat3DFragShaderFull.GLSL";
                              tfv = { "gl_Position", "oSig", "oColor", "oFragPos", "oFaulty" }; }                          // 17 floats
@@ -249,7 +251,7 @@ static int cmd_draw(int argc, char** argv) {
         glGenBuffers(1, &ssbo_data); glBindBuffer(GL_SHADER_STORAGE_BUFFER, ssbo_data);
         glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)rec.size(), rec.data(), GL_DYNAMIC_DRAW);        // ShareStorageBuffer.cpp:3-8
     }
-    if (kind == "4d") {
+    if (kind == "4d" && !mod) {
         std::vector<uint32_t> si((size_t)n);
         if (sortpath == "-") for (long i = 0; i < n; ++i) si[i] = (uint32_t)i;
         else { std::vector<uint8_t> b = slurp(sortpath); if (b.size() != 4 * (size_t)n) die("sortidx size"); memcpy(si.data(), b.data(), b.size()); }
@@ -266,7 +268,8 @@ static int cmd_draw(int argc, char** argv) {
         if (kind == "4d") { glUniform1f(uni(prog, "uTime"), u[0]); glUniform1f(uni(prog, "uMinOpacity"), u[1]); }   // :331-332
         if (kind != "2d") glUniformMatrix4fv(uni(prog, "uView"), 1, GL_FALSE, u + 2);                        // :333 (2d: uView is unused => optimised out)
         glUniformMatrix4fv(uni(prog, "uProj"), 1, GL_FALSE, u + 18);                                         // :334
-        if (kind == "4d") { glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 1, ssbo_idx); glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 2, ssbo_data); }   // :336-337
+        if (kind == "4d" && !mod) { glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 1, ssbo_idx); glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 2, ssbo_data); }   // :336-337
+        if (mod) glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 1, ssbo_data);                                   // Scenes.h:1806
         if (kind == "2d") glBindBufferBase(GL_SHADER_STORAGE_BUFFER, 1, ssbo_data);                          // Scenes.h Gaussians2D::Render
     };
     auto issue = [&]() {

@@ -9,7 +9,7 @@ import pytest
 
 import gl_cases as gl
 
-MODES = {"4d": 0, "3d": 2, "2d": 3}
+MODES = {"4d": 0, "4dmod": 0, "3d": 2, "2d": 3}          # 4dmod: Splat4DVertexShaderMod.GLSL — the same arithmetic, instance k draws record k
 
 
 def test_fixture_files_match_manifest():
