@@ -250,6 +250,10 @@ def main():
     p4, q4, s4, life, fade, vel, col4 = scenes.cube_params_4d(4096)
     cube4 = gs4d.build_records_4d(p4, q4, s4, life, fade, vel, col4)
     vs_fixture("gl_vs_cube4d4096", "4d", cube4, 25.0, 0.0, v, p, 1920, 1080, True, "scenes.cube_params_4d(4096) -> build_records_4d, t = 25")
+    # BASELINE.json configs[4]'s frame size: the viewport transform at 3840 x 2160 (window coordinates up to 3840: float32 steps of 2.4e-4 px)
+    v4k, p4k = VP(cam_c, 3840, 2160)
+    vs_fixture("gl_vs_cube4d4096_4k", "4d", cube4, 25.0, 0.0, v4k, p4k, 3840, 2160, False, "gl_vs_cube4d4096 (its records), 3840 x 2160")
+    vs_fixture("gl_vs_cube4096_4k", "4d", cube, 0.0, 0.0, v4k, p4k, 3840, 2160, False, "gl_vs_cube4096 (its records), 3840 x 2160")
     # a camera inside the cube: many records behind it or outside the 1.2 bound -> the cull branch and the quad z-clip
     cam_in = ((20.0, -35.0, 10.0), (0.3, 0.2, -1.0))
     v, p = VP(cam_in, 1280, 720)

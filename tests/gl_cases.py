@@ -42,6 +42,8 @@ def records(fix, name, golden):
     if "records" in fix:
         return fix["records"]
     src = manifest()[name]["source"].split(" ")[0].rstrip(",")
+    if src.startswith("gl_"):                                   # the records embedded in another fixture
+        return load(src)["records"]
     if src == "splat_draw_3d_in":
         import splat_draw_cases as sd
         return sd.verts72(golden(src))
