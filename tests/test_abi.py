@@ -42,3 +42,37 @@ def test_no_cpu_fallback_without_gpu(gs4d):
     with pytest.raises(gs4d.Gs4dError) as e:
         gs4d.Context(64, 64)
     assert "no HIP device" in str(e.value)
+
+
+def test_header_is_plain_c_and_a_c_program_links(gs4d, tmp_path):
+    """The boundary is a C ABI: include/gs4d.h compiles as C99 (-pedantic) and a C program that names entry points links against libgs4d.so and
+    runs here — a CPU-only host: gs4d_create must fail with an error code, not crash, and the host-side entry points work without a GPU
+    (Camera.cpp:55-58 -> gs4d_host_perspective)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no C compiler")
+    src = tmp_path / "c_abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "gs4d.h"
+int main(void) {
+    float P[16];
+    gs4d_ctx* ctx = NULL;
+    int rc;
+    gs4d_host_perspective(60.0f, 1920, 1080, 0.1f, 5000.0f, P);
+    if (!(P[0] > 0.0f && P[5] > 0.0f && P[11] == -1.0f)) return 2;
+    rc = gs4d_create(0, 64, 64, &ctx);
+    printf("%s rc=%d\n", gs4d_version(), rc);
+    if (rc == GS4D_OK && ctx) gs4d_destroy(ctx);
+    return 0;
+}
+''')
+    exe = tmp_path / "c_abi"
+    libdir = os.path.dirname(gs4d.LIB_PATH)
+    cc = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                         "-L", libdir, "-lgs4d", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib"], capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr[-500:])
+    assert "rc=" in run.stdout
